@@ -69,7 +69,7 @@ typedef enum { VDB_OP_EQ = 0, VDB_OP_NEQ = 1, VDB_OP_LT = 2, VDB_OP_LTE = 3, VDB
 typedef enum {
     VDB_T_INT = 0, VDB_T_FLOAT = 1, VDB_T_STR = 2, VDB_T_BOOL = 3,
     VDB_T_LIST_INT = 4, VDB_T_LIST_FLOAT = 5, VDB_T_LIST_STR = 6, VDB_T_LIST_BOOL = 7
-} vdb_value_type;
+} vdb_value_kind;
 
 /* ListQueryOp, src/utils/payload.rs:141-147 */
 typedef enum { VDB_LQ_CONTAINS = 0, VDB_LQ_EQUALS = 1, VDB_LQ_LENGTH = 2, VDB_LQ_ELEMENT_COMPARE = 3 } vdb_list_query;
@@ -125,8 +125,9 @@ vdb_status vdb_score(const float* a, size_t na, const float* b, size_t nb, vdb_m
 /* Fused streaming scan (extension): out[q*n + i] = score(queries[q], base[i]) for host buffers. */
 vdb_status vdb_score_scan(const float* queries, size_t nq, const float* base, size_t n, size_t dim,
                           vdb_metric metric, vdb_arith arith, int device, float* out);
-/* Same on device-resident buffers (row stride = dim floats), enqueued on `stream` (hipStream_t). */
-vdb_status vdb_score_scan_dev(const float* d_queries, size_t nq, const float* d_base, size_t n, size_t dim,
+/* Same on device-resident buffers: queries dense (dim floats each), base rows `stride` floats apart
+ * (FAST needs 16-byte aligned rows zero-padded to a multiple of 4 floats); enqueued on `stream`. */
+vdb_status vdb_score_scan_dev(const float* d_queries, size_t nq, const float* d_base, size_t n, size_t dim, size_t stride,
                               vdb_metric metric, vdb_arith arith, float* d_out, void* stream);
 
 /* ---------------------------------------------------------------- payload.rs -------------- */

@@ -39,7 +39,7 @@ def be(request):
     return api
 
 
-@pytest.fixture(params=["oracle"])
+@pytest.fixture(params=["oracle", "hip"])
 def hostbe(request):
     """Host-only logic (payloads, filters, inverted index): no GPU compute behind these calls."""
     api = _backend(request, request.param)

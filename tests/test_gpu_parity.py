@@ -1,0 +1,198 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs and
+the SAME graph.  Bars: STRICT arithmetic is bit-exact in ids and scores on continuous random data;
+FAST arithmetic matches ids outside near-ties (<= 1e-6 relative key gap) and scores to 1e-5 relative."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-5          # north-star tolerance for distances
+TIE = 1e-6          # relative key gap below which an id swap is a tie, not a mismatch
+
+
+def data(n, d, seed, kind="uniform"):
+    rng = np.random.default_rng(seed)
+    if kind == "uniform":
+        return rng.uniform(-1, 1, size=(n, d)).astype(np.float32)
+    centres = rng.uniform(0, 128, size=(32, d))
+    x = centres[rng.integers(0, 32, size=n)] + rng.normal(0, 12, size=(n, d))
+    return np.clip(x, 0, None).astype(np.float32)
+
+
+def rel_close(a, b, tol=REL):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.all(np.abs(a - b) <= tol * np.maximum(1e-6, np.maximum(np.abs(a), np.abs(b))))
+
+
+@pytest.mark.parametrize("dim", [1, 3, 4, 5, 32, 96, 128, 130, 768, 960])
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_score_scan_strict_bitwise_and_fast_close(ora, vdb, dim, metric):
+    q = data(9, dim, 1); b = data(257, dim, 2)
+    ref = ora.score_scan(q, b, metric)
+    got = vdb.score_scan(q, b, metric, arith=vdb.Arith.Strict)
+    assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), f"strict scan differs (max abs {np.abs(ref-got).max()})"
+    fast = vdb.score_scan(q, b, metric, arith=vdb.Arith.Fast)
+    # relative to the magnitude the sum is built from: 1 for a cosine distance, |q||b| for a dot
+    # product (which cancels towards 0), the distance itself for L2
+    if metric == 0: scale = np.ones_like(ref)
+    elif metric == 1: scale = np.linalg.norm(q, axis=1)[:, None] * np.linalg.norm(b, axis=1)[None, :]
+    else: scale = np.abs(ref)
+    assert np.all(np.abs(fast - ref) <= REL * np.maximum(scale, 1e-6)), (np.abs(fast - ref) / np.maximum(scale, 1e-6)).max()
+
+
+def test_score_single_pair_matches_oracle_bitwise(ora, vdb):
+    rng = np.random.default_rng(5)
+    for metric in (0, 1, 2):
+        for d in (2, 3, 7, 64):
+            a = rng.normal(size=d).astype(np.float32); b = rng.normal(size=d).astype(np.float32)
+            assert np.float32(ora.score(a, b, metric)).view(np.uint32) == np.float32(vdb.score(a, b, metric)).view(np.uint32)
+
+
+def build_oracle(ora, metric, n, d, seed, m=16, ef=64, kind="uniform"):
+    x = data(n, d, seed, kind)
+    h = ora.HNSWIndex(metric, m, ef, 16, d, seed=seed)
+    for i in range(n):
+        h.insert(i * 3 + 1, x[i])            # ids are not slot numbers
+    return h, x
+
+
+def compare_results(ref, refn, got, gotn, exact):
+    assert np.array_equal(refn, gotn)
+    bad = 0
+    for r, g, n in zip(ref, got, refn):
+        r, g = r[:n], g[:n]
+        if exact:
+            assert np.array_equal(r["id"], g["id"]) and np.array_equal(r["raw_score"].view(np.uint32), g["raw_score"].view(np.uint32)) \
+                and np.array_equal(r["sort_key"].view(np.uint32), g["sort_key"].view(np.uint32))
+            continue
+        assert rel_close(r["sort_key"], g["sort_key"], 4 * REL)
+        for j in np.nonzero(r["id"] != g["id"])[0]:
+            # an id may only move within a run of near-equal keys
+            k = r["sort_key"][j]
+            near = np.abs(r["sort_key"] - k) <= 1e-4 * max(abs(k), 1e-6)
+            if g["id"][j] not in r["id"][near]:
+                bad += 1
+    return bad
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("dim,kind", [(32, "uniform"), (128, "clustered"), (100, "uniform")])
+def test_search_same_graph_strict_exact_fast_close(ora, vdb, metric, dim, kind):
+    n, nq, k = 3000, 200, 10
+    h, x = build_oracle(ora, metric, n, dim, seed=7 + metric, kind=kind)
+    g = h.export_graph()
+    q = data(nq, dim, 99, kind)
+    ref, refn, rst = h.search_batch(q, k, with_stats=True)
+    for arith in (vdb.Arith.Strict, vdb.Arith.Fast):
+        p = vdb.HNSWIndex(metric, 16, 64, 16, dim, seed=1, arith=arith)
+        p.import_graph(g)
+        got, gotn, st = p.search_batch(q, k, with_stats=True)
+        bad = compare_results(ref, refn, got, gotn, exact=(arith == vdb.Arith.Strict))
+        assert bad <= nq * k // 200, f"{bad} ids differ beyond near-ties"
+        if arith == vdb.Arith.Strict:
+            # the traversal is the same one: identical work counters
+            assert np.array_equal(rst["expanded"], st["expanded"])
+    # other beam widths on the same graph
+    for ef in (16, 128, 300):
+        ref, refn = h.search_batch(q[:50], 20, ef_search=ef)
+        p = vdb.HNSWIndex(metric, 16, 64, 16, dim, seed=1, arith=vdb.Arith.Strict)
+        p.import_graph(g)
+        got, gotn = p.search_batch(q[:50], 20, ef_search=ef)
+        compare_results(ref, refn, got, gotn, exact=True)
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_single_insert_builds_the_same_graph(ora, vdb, metric):
+    """Graph producer parity (hnsw.rs:119-208): same seed, same points, STRICT arithmetic -> identical lists."""
+    n, d = 400, 24
+    x = data(n, d, 21)
+    ho = ora.HNSWIndex(metric, 8, 32, 16, d, seed=5)
+    hp = vdb.HNSWIndex(metric, 8, 32, 16, d, seed=5, arith=vdb.Arith.Strict)
+    for i in range(n):
+        ho.insert(i + 10, x[i]); hp.insert(i + 10, x[i])
+    go, gp = ho.export_graph(), hp.export_graph()
+    assert go["entry"] == gp["entry"] and go["current_max_level"] == gp["current_max_level"]
+    assert np.array_equal(go["levels"], gp["levels"])
+    assert np.array_equal(go["vectors"].view(np.uint32), gp["vectors"].view(np.uint32))
+    assert len(go["layers"]) == len(gp["layers"])
+    for (ow, of, nb), (ow2, of2, nb2) in zip(go["layers"], gp["layers"]):
+        assert np.array_equal(ow, ow2) and np.array_equal(of, of2) and np.array_equal(nb, nb2)
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_exact_knn_bit_exact(ora, vdb, metric):
+    n, d, nq, k = 5000, 48, 64, 10
+    h, x = build_oracle(ora, metric, 200, d, seed=3)          # small graph; exact k-NN ignores it
+    g = h.export_graph()
+    # grow the point set without graph edges: exact k-NN scans rows only
+    xs = data(n, d, 8)
+    if metric == 0:
+        xs = xs / np.linalg.norm(xs, axis=1, keepdims=True).astype(np.float32)
+    g2 = dict(g); g2["ids"] = np.arange(n, dtype=np.uint64) * 2 + 5; g2["levels"] = np.zeros(n, np.uint32)
+    g2["vectors"] = xs; g2["deleted"] = np.zeros(n, np.uint8); g2["deleted"][::17] = 1
+    g2["layers"] = []; g2["entry"] = 5 + 2; g2["current_max_level"] = 0
+    ho = ora.HNSWIndex(metric, 16, 64, 16, d); ho.import_graph(g2)
+    hp = vdb.HNSWIndex(metric, 16, 64, 16, d); hp.import_graph(g2)
+    q = data(nq, d, 4)
+    ref, refn = ho.exact_knn_batch(q, k)
+    got, gotn = hp.exact_knn_batch(q, k)
+    assert np.array_equal(refn, gotn)
+    assert np.array_equal(ref["id"], got["id"])
+    assert np.array_equal(ref["raw_score"].view(np.uint32), got["raw_score"].view(np.uint32))
+    deleted_ids = set(g2["ids"][::17].tolist())
+    assert not (set(got["id"].ravel().tolist()) & deleted_ids)
+
+
+def test_exact_knn_ties_break_by_id(ora, vdb):
+    d = 8
+    base = np.zeros((40, d), np.float32); base[:, 0] = np.repeat(np.arange(10), 4)     # 4-way exact ties
+    ids = np.array([100 - i for i in range(40)], dtype=np.uint64)                      # descending ids
+    g = dict(ids=ids, levels=np.zeros(40, np.uint32), vectors=base, deleted=np.zeros(40, np.uint8), layers=[], entry=int(ids[0]), current_max_level=0)
+    ho = ora.HNSWIndex(2, 16, 64, 16, d); ho.import_graph(g)
+    hp = vdb.HNSWIndex(2, 16, 64, 16, d); hp.import_graph(g)
+    q = np.zeros((1, d), np.float32)
+    ref, _ = ho.exact_knn_batch(q, 10); got, _ = hp.exact_knn_batch(q, 10)
+    assert np.array_equal(ref["id"], got["id"])
+    assert list(got["id"][0][:4]) == sorted(got["id"][0][:4])
+
+
+def test_deleted_points_and_fallback_entry(ora, vdb):
+    metric, d = 2, 16
+    h, x = build_oracle(ora, metric, 800, d, seed=12)
+    g = h.export_graph()
+    p = vdb.HNSWIndex(metric, 16, 64, 16, d, arith=vdb.Arith.Strict); p.import_graph(g)
+    rng = np.random.default_rng(0)
+    kill = rng.choice(g["ids"], size=200, replace=False)
+    kill = np.concatenate([kill, [h.get_entry_point()]])          # tombstone the entry too (hnsw.rs:114-116)
+    for pid in kill:
+        h.mark_deleted(int(pid)); p.mark_deleted(int(pid))
+    assert h.get_entry_point() == p.get_entry_point()
+    q = data(100, d, 77)
+    ref, refn = h.search_batch(q, 10); got, gotn = p.search_batch(q, 10)
+    compare_results(ref, refn, got, gotn, exact=True)
+    assert not (set(got["id"].ravel().tolist()) & set(int(v) for v in kill))
+
+
+def test_topk_merge_matches_oracle(ora, vdb):
+    import ctypes as C
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(3)
+    S, Q, K = 4, 37, 10
+    lists = np.zeros((S, Q, K), dtype=vdb.SCORED_DTYPE); counts = rng.integers(0, K + 1, size=(S, Q)).astype(np.uint32)
+    for s in range(S):
+        for q in range(Q):
+            keys = np.sort(rng.integers(0, 30, size=K).astype(np.float32))      # many cross-shard ties
+            lists[s, q]["sort_key"] = keys; lists[s, q]["raw_score"] = keys
+            lists[s, q]["id"] = rng.permutation(1000)[:K] + s * 1000
+            o = np.lexsort((lists[s, q]["id"], lists[s, q]["sort_key"])); lists[s, q] = lists[s, q][o]
+    ref = np.zeros((Q, K), dtype=vdb.SCORED_DTYPE); refn = np.zeros(Q, np.uint32)
+    ora.check(ora.fn.topk_merge(lists.ctypes.data, counts.ctypes.data, S, Q, K, ref.ctypes.data, refn.ctypes.data))
+    dl = torch.from_numpy(lists.view(np.uint8).reshape(-1)).cuda(); dc = torch.from_numpy(counts.view(np.int32).reshape(-1)).cuda()
+    do = torch.zeros(Q * K * 16, dtype=torch.uint8, device="cuda"); dn = torch.zeros(Q, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    vdb.check(vdb.fn.topk_merge_dev(dl.data_ptr(), dc.data_ptr(), S, Q, K, do.data_ptr(), dn.data_ptr(), None))
+    torch.cuda.synchronize()
+    got = do.cpu().numpy().view(vdb.SCORED_DTYPE).reshape(Q, K); gotn = dn.cpu().numpy().view(np.uint32)
+    assert np.array_equal(refn, gotn)
+    for q in range(Q):
+        assert np.array_equal(ref[q][: refn[q]], got[q][: gotn[q]])

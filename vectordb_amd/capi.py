@@ -194,7 +194,7 @@ _SIGS = {
     "segment_in_place_filtered_search": (_I, [_VP, _VP, _SZ, _SZ, _VP, _VP, _PSZ]),
     "segment_compile_filter": (_I, [_VP, _VP, _PSZ, _PSZ]),
     "topk_merge_dev": (_I, [_VP, _VP, _SZ, _SZ, _SZ, _VP, _VP, _VP]),
-    "score_scan_dev": (_I, [_VP, _SZ, _VP, _SZ, _SZ, _I, _I, _VP, _VP]),
+    "score_scan_dev": (_I, [_VP, _SZ, _VP, _SZ, _SZ, _SZ, _I, _I, _VP, _VP]),
     "default_options": (None, [_VP]),
 }
 # entry points that only some libraries export (host-buffer helpers of the checker)

@@ -1,0 +1,557 @@
+// Host side of the HNSW index: the literal graph the reference keeps (lists with self links and
+// duplicates), the linking rules of hnsw.rs:119-208, and the device-resident packed copy every
+// distance computation runs against.
+#include "index.hpp"
+
+#include <cmath>
+#include <cstring>
+
+using namespace vdb;
+
+namespace {
+thread_local std::string g_last_error;
+}
+void vdb::set_last_error(const std::string& s) { g_last_error = s; }
+extern "C" const char* vdb_last_error_message(void) { return g_last_error.c_str(); }
+
+// ------------------------------------------------------------------------------------------------
+vdb_index::vdb_index(vdb_metric metric_, size_t m_, size_t ef_, size_t cap_, size_t dim_, const vdb_options& o)
+    : metric(metric_), m(m_), ef(ef_), max_level_cap(cap_), dim(dim_), level_scale(1.0 / std::log((double)m_)), opts(o) {   // hnsw.rs:77-94
+    if (dim == 0 || dim > MAX_DIM) throw Failure(err_arg("dim must be in 1..2048"));
+    if (ef == 0 || ef > MAX_EF) throw Failure(err_arg("ef must be in 1..1024"));
+    if (m == 0) throw Failure(err_arg("m must be positive"));
+    stride = (uint32_t)((dim + 3) & ~size_t(3));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw Failure(err_device("no HIP device available; libvdbmi has no CPU path"));
+    if (opts.device < 0 || opts.device >= ndev) throw Failure(err_device("device ordinal out of range"));
+    use_device();
+    VDB_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+}
+
+vdb_index::~vdb_index() {
+    if (stream) { (void)hipSetDevice(opts.device); (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+}
+
+void vdb_index::use_device() const { VDB_HIP(hipSetDevice(opts.device)); }
+
+const std::vector<uint32_t>* vdb_index::list(size_t level, uint32_t slot) const {
+    if (level >= layers.size()) return nullptr;
+    const HostLayer& L = layers[level];
+    if (slot >= L.idx.size() || L.idx[slot] < 0) return nullptr;
+    return &L.lists[L.idx[slot]];
+}
+
+std::vector<uint32_t>& vdb_index::list_or_default(size_t level, uint32_t slot) {
+    if (layers.size() <= level) layers.resize(level + 1);
+    HostLayer& L = layers[level];
+    if (L.idx.size() <= slot) L.idx.resize(std::max<size_t>(slot + 1, ids.size()), -1);
+    if (L.idx[slot] < 0) { L.idx[slot] = (int32_t)L.lists.size(); L.lists.emplace_back(); L.owner.push_back(slot); }
+    graph_dirty = true;
+    return L.lists[L.idx[slot]];
+}
+
+std::optional<uint32_t> vdb_index::first_live_slot() const {       // DET-1
+    if (live.empty()) return std::nullopt;
+    return slot_of.at(*live.begin());
+}
+
+size_t vdb_index::draw_level() {                                    // hnsw.rs:96-101
+    const uint64_t h = rng_draw(opts.seed, 1, level_draws++);
+    const double r = (double)(h >> 11) * (1.0 / 9007199254740992.0);
+    const double x = std::floor(-std::log(r) * level_scale);
+    size_t l;
+    if (!(x == x) || x <= 0) l = 0;
+    else if (x >= 1.8446744073709552e19) l = SIZE_MAX;
+    else l = (size_t)x;
+    return std::min(l, max_level_cap);
+}
+
+// Appends rows to the host mirror and the device (normalised on the device for Cosine,
+// hnsw.rs:138-139), draws levels and creates the self links of hnsw.rs:143-148.
+uint32_t vdb_index::append_rows(const uint64_t* pids, const float* v, size_t n) {
+    use_device();
+    const uint32_t first = (uint32_t)ids.size();
+    const size_t total = ids.size() + n;
+    if (total >= 0x7FFFFFFFull) throw Failure(err_arg("more than 2^31 points in one index"));
+    d_vecs.reserve(total * stride, stream);
+    std::vector<float> padded(n * stride, 0.f);
+    for (size_t i = 0; i < n; ++i) std::memcpy(&padded[i * stride], v + i * dim, dim * sizeof(float));
+    VDB_HIP(hipMemcpyAsync(d_vecs.p + (size_t)first * stride, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    if (metric == VDB_COSINE) {
+        launch_normalize_rows(d_vecs.p, stride, (uint32_t)dim, first, (uint32_t)n, stream);
+        VDB_HIP(hipMemcpyAsync(padded.data(), d_vecs.p + (size_t)first * stride, padded.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+    }
+    VDB_HIP(hipStreamSynchronize(stream));
+    hvecs.resize(total * dim);
+    for (size_t i = 0; i < n; ++i) std::memcpy(&hvecs[(first + i) * dim], &padded[i * stride], dim * sizeof(float));
+    d_ids.reserve(total, stream);
+    VDB_HIP(hipMemcpyAsync(d_ids.p + first, pids, n * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    VDB_HIP(hipStreamSynchronize(stream));
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t s = first + (uint32_t)i;
+        ids.push_back(pids[i]); slot_of[pids[i]] = s; deleted.push_back(0); live.insert(pids[i]);
+        const size_t level = draw_level();
+        levels.push_back((uint32_t)level);
+        for (size_t l = 0; l <= level; ++l) list_or_default(l, s).push_back(s);
+    }
+    rows_on_device = total;
+    graph_dirty = true; deleted_dirty = true;
+    return first;
+}
+
+std::vector<float> vdb_index::maybe_normalize(const float* v) {     // hnsw.rs:752-764
+    std::vector<float> out(v, v + dim);
+    if (metric != VDB_COSINE) return out;
+    std::lock_guard<std::mutex> lk(mu);
+    use_device();
+    s_q.reserve(stride, stream, false);
+    std::vector<float> padded(stride, 0.f);
+    std::memcpy(padded.data(), v, dim * sizeof(float));
+    VDB_HIP(hipMemcpyAsync(s_q.p, padded.data(), stride * sizeof(float), hipMemcpyHostToDevice, stream));
+    launch_normalize_rows(s_q.p, stride, (uint32_t)dim, 0, 1, stream);
+    VDB_HIP(hipMemcpyAsync(padded.data(), s_q.p, stride * sizeof(float), hipMemcpyDeviceToHost, stream));
+    VDB_HIP(hipStreamSynchronize(stream));
+    std::memcpy(out.data(), padded.data(), dim * sizeof(float));
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Device copy of the graph: rows are already resident; lists are packed with self loops and
+// duplicate ids removed (the visited set makes both invisible to every search, hnsw.rs:475).
+void vdb_index::sync_device() {
+    use_device();
+    const size_t n = ids.size();
+    if (graph_dirty) {
+        std::vector<uint64_t> desc0(n, make_desc(0, 0)), udesc;
+        std::vector<uint32_t> upper_base(n, NONE32), pool;
+        std::vector<uint8_t> upper_cnt(n, 0);
+        std::vector<uint32_t> stamp(n, 0); uint32_t epoch = 0;
+        auto pack = [&](const std::vector<uint32_t>& src, uint32_t self) -> uint64_t {
+            ++epoch;
+            const uint64_t off = pool.size();
+            for (uint32_t x : src) { if (x == self || stamp[x] == epoch) continue; stamp[x] = epoch; pool.push_back(x); }
+            return make_desc(off, (uint32_t)(pool.size() - off));
+        };
+        size_t reserve_edges = 0;
+        for (auto& L : layers) for (auto& l : L.lists) reserve_edges += l.size();
+        pool.reserve(reserve_edges);
+        if (!layers.empty()) {
+            const HostLayer& L0 = layers[0];
+            for (size_t k = 0; k < L0.lists.size(); ++k) desc0[L0.owner[k]] = pack(L0.lists[k], L0.owner[k]);
+        }
+        l0_edges = pool.size();
+        // upper layers: a slot's descriptors for layers 1..cnt are consecutive in udesc
+        for (size_t l = 1; l < layers.size(); ++l)
+            for (uint32_t s : layers[l].owner) upper_cnt[s] = std::max<uint8_t>(upper_cnt[s], (uint8_t)std::min<size_t>(l, 255));
+        for (uint32_t s = 0; s < n; ++s) {
+            if (!upper_cnt[s]) continue;
+            upper_base[s] = (uint32_t)udesc.size();
+            for (size_t l = 1; l <= upper_cnt[s]; ++l) {
+                const std::vector<uint32_t>* lst = list(l, s);
+                udesc.push_back(lst ? pack(*lst, s) : make_desc(0, 0));
+            }
+        }
+        upper_edges = pool.size() - l0_edges;
+        d_desc0.reserve(std::max<size_t>(n, 1), stream, false); d_upper_base.reserve(std::max<size_t>(n, 1), stream, false);
+        d_upper_cnt.reserve(std::max<size_t>(n, 1), stream, false);
+        d_udesc.reserve(std::max<size_t>(udesc.size(), 1), stream, false); d_pool.reserve(std::max<size_t>(pool.size(), 1), stream, false);
+        if (n) {
+            VDB_HIP(hipMemcpyAsync(d_desc0.p, desc0.data(), n * 8, hipMemcpyHostToDevice, stream));
+            VDB_HIP(hipMemcpyAsync(d_upper_base.p, upper_base.data(), n * 4, hipMemcpyHostToDevice, stream));
+            VDB_HIP(hipMemcpyAsync(d_upper_cnt.p, upper_cnt.data(), n, hipMemcpyHostToDevice, stream));
+        }
+        if (!udesc.empty()) VDB_HIP(hipMemcpyAsync(d_udesc.p, udesc.data(), udesc.size() * 8, hipMemcpyHostToDevice, stream));
+        if (!pool.empty()) VDB_HIP(hipMemcpyAsync(d_pool.p, pool.data(), pool.size() * 4, hipMemcpyHostToDevice, stream));
+        VDB_HIP(hipStreamSynchronize(stream));
+        device_bytes = n * (size_t)stride * 4 + n * 8 + n * 8 + n * 5 + udesc.size() * 8 + pool.size() * 4;
+        graph_dirty = false;
+    }
+    if (deleted_dirty) {
+        if (n_deleted) {
+            std::vector<uint32_t> bits((n + 31) / 32, 0);
+            for (size_t s = 0; s < n; ++s) if (deleted[s]) bits[s >> 5] |= 1u << (s & 31);
+            d_deleted.reserve(bits.size(), stream, false);
+            VDB_HIP(hipMemcpyAsync(d_deleted.p, bits.data(), bits.size() * 4, hipMemcpyHostToDevice, stream));
+            VDB_HIP(hipStreamSynchronize(stream));
+        }
+        deleted_dirty = false;
+    }
+}
+
+GraphView vdb_index::view() const {
+    GraphView g{};
+    g.vecs = d_vecs.p; g.stride = stride; g.dim = (uint32_t)dim; g.n = (uint32_t)ids.size();
+    g.ids = d_ids.p; g.desc0 = d_desc0.p; g.upper_base = d_upper_base.p; g.upper_cnt = d_upper_cnt.p;
+    g.udesc = d_udesc.p; g.pool = d_pool.p; g.deleted = n_deleted ? d_deleted.p : nullptr; g.metric = (int)metric;
+    return g;
+}
+
+uint32_t vdb_index::pick_hash_log2(size_t ef_, bool& global) const {
+    // visited nodes per query grow roughly linearly with ef; 48 slots per beam entry keeps the
+    // LDS table under 3/4 full on the graphs measured, larger beams use a table in HBM
+    size_t want = std::max<size_t>(1024, ef_ * 48);
+    uint32_t lg = 10;
+    while ((size_t(1) << lg) < want) ++lg;
+    global = lg > 13;
+    if (global) lg = std::max<uint32_t>(lg + 1, 16);
+    return lg;
+}
+
+// Launches the search and, when the visited table overflowed for some queries, repeats those
+// with a larger table in HBM.
+void vdb_index::run_search(SearchArgs a, size_t nq, hipStream_t s, bool retry_on_overflow, const float* d_q_all) {
+    bool global = false;
+    a.hash_log2 = pick_hash_log2(a.ef, global);
+    a.hash_global = nullptr;
+    if (global) {
+        s_hash.reserve(nq << a.hash_log2, s, false);
+        a.hash_global = s_hash.p;
+    }
+    launch_search(a, s);
+    if (!retry_on_overflow) return;
+    std::vector<vdb_query_stats> st(nq);
+    VDB_HIP(hipMemcpyAsync(st.data(), a.stats, nq * sizeof(vdb_query_stats), hipMemcpyDeviceToHost, s));
+    VDB_HIP(hipStreamSynchronize(s));
+    std::vector<uint32_t> redo;
+    for (size_t i = 0; i < nq; ++i) if (st[i].flags & QF_HASH_OVERFLOW) redo.push_back((uint32_t)i);
+    uint32_t lg = std::max<uint32_t>(a.hash_log2 + 3, 16);
+    while (!redo.empty()) {
+        if (lg > 26) throw Failure(err_device("visited table overflow beyond 2^26 entries"));
+        // one query at a time keeps the scratch table bounded
+        s_hash.reserve(size_t(1) << lg, s, false);
+        for (uint32_t qi : redo) {
+            SearchArgs b = a;
+            b.nq = 1; b.hash_log2 = lg; b.hash_global = s_hash.p;
+            if (b.queries) b.queries = d_q_all + (size_t)qi * dim;
+            if (b.query_slots) b.query_slots = a.query_slots + qi;
+            if (b.q_levels) { b.q_levels = a.q_levels + qi; b.nb_off = a.nb_off + qi; }
+            if (b.q_entry) b.q_entry = a.q_entry + qi;
+            if (b.cand_scratch) b.cand_scratch = a.cand_scratch + (size_t)qi * a.cand_cap;
+            b.out = a.out ? a.out + (size_t)qi * a.top_k : nullptr; b.out_n = a.out_n + qi; b.stats = a.stats + qi;
+            // nb_off is absolute, so the single-query launch must not re-base it: handled by the
+            // kernel reading nb_off[q] with q == 0 at the shifted pointer.
+            launch_search(b, s);
+        }
+        VDB_HIP(hipMemcpyAsync(st.data(), a.stats, nq * sizeof(vdb_query_stats), hipMemcpyDeviceToHost, s));
+        VDB_HIP(hipStreamSynchronize(s));
+        std::vector<uint32_t> again;
+        for (uint32_t qi : redo) if (st[qi].flags & QF_HASH_OVERFLOW) again.push_back(qi);
+        redo.swap(again); lg += 3;
+    }
+}
+
+void vdb_index::search_batch(const float* q, size_t nq, size_t top_k, size_t ef_search, const FilterArgs& fa,
+                             vdb_scored_point* out, uint32_t* out_n, vdb_query_stats* stats) {
+    if (nq == 0) return;
+    std::lock_guard<std::mutex> lk(mu);
+    use_device();
+    const size_t ef_ = ef_search ? ef_search : ef;
+    if (ef_ > MAX_EF) throw Failure(err_arg("ef_search must be <= 1024"));
+    if (!entry_point && fa.entry_slot == NONE32) {                                   // hnsw.rs:515-518
+        std::memset(out_n, 0, nq * sizeof(uint32_t));
+        if (stats) std::memset(stats, 0, nq * sizeof(vdb_query_stats));
+        return;
+    }
+    if (top_k == 0) { std::memset(out_n, 0, nq * sizeof(uint32_t)); return; }
+    sync_device();
+    s_q.reserve(nq * dim, stream, false); s_out.reserve(nq * top_k, stream, false);
+    s_n.reserve(nq, stream, false); s_stats.reserve(nq, stream, false);
+    VDB_HIP(hipMemcpyAsync(s_q.p, q, nq * dim * sizeof(float), hipMemcpyHostToDevice, stream));
+    SearchArgs a{};
+    a.g = view(); a.mode = fa.mode; a.arith = opts.arith; a.queries = s_q.p; a.nq = (uint32_t)nq;
+    a.entry = fa.entry_slot != NONE32 ? fa.entry_slot : slot_of.at(*entry_point);
+    a.max_level = (uint32_t)current_max_level;
+    auto fl = first_live_slot(); a.fallback_live = fl ? *fl : NONE32;
+    a.ef = (uint32_t)ef_; a.top_k = (uint32_t)top_k; a.out = s_out.p; a.out_n = s_n.p; a.stats = s_stats.p;
+    if (fa.bits) { a.pass_bits = fa.bits->d_pass.p; a.err_bits = fa.bits->d_err.p; }
+    if (fa.mode == MODE_LITERAL) {
+        a.cand_cap = 16384;
+        s_cand.reserve(nq * a.cand_cap, stream, false);
+        a.cand_scratch = s_cand.p;
+    }
+    run_search(a, nq, stream, true, s_q.p);
+    std::vector<vdb_query_stats> st(nq);
+    VDB_HIP(hipMemcpyAsync(out, s_out.p, nq * top_k * sizeof(vdb_scored_point), hipMemcpyDeviceToHost, stream));
+    VDB_HIP(hipMemcpyAsync(out_n, s_n.p, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    VDB_HIP(hipMemcpyAsync(st.data(), s_stats.p, nq * sizeof(vdb_query_stats), hipMemcpyDeviceToHost, stream));
+    VDB_HIP(hipStreamSynchronize(stream));
+    for (size_t i = 0; i < nq; ++i) {
+        if (st[i].flags & QF_CAND_OVERFLOW) throw Failure(err_device("filtered search candidate queue overflow"));
+        if (st[i].flags & QF_FILTER_ERROR) throw Failure(Error{VDB_ERR_INVALID_PAYLOAD, "@slot:" + std::to_string(st[i].expanded)});
+    }
+    if (stats) std::memcpy(stats, st.data(), nq * sizeof(vdb_query_stats));
+}
+
+void vdb_index::search_batch_dev(const float* d_q, size_t nq, size_t top_k, size_t ef_search, vdb_scored_point* d_out, uint32_t* d_out_n,
+                                 vdb_query_stats* d_stats, hipStream_t s) {
+    if (nq == 0) return;
+    std::lock_guard<std::mutex> lk(mu);
+    use_device();
+    if (!s) s = stream;
+    const size_t ef_ = ef_search ? ef_search : ef;
+    if (ef_ > MAX_EF) throw Failure(err_arg("ef_search must be <= 1024"));
+    if (!entry_point) { VDB_HIP(hipMemsetAsync(d_out_n, 0, nq * sizeof(uint32_t), s)); return; }
+    sync_device();
+    SearchArgs a{};
+    a.g = view(); a.mode = MODE_SEARCH; a.arith = opts.arith; a.queries = d_q; a.nq = (uint32_t)nq;
+    a.entry = slot_of.at(*entry_point); a.max_level = (uint32_t)current_max_level;
+    auto fl = first_live_slot(); a.fallback_live = fl ? *fl : NONE32;
+    a.ef = (uint32_t)ef_; a.top_k = (uint32_t)top_k; a.out = d_out; a.out_n = d_out_n; a.stats = d_stats;
+    // no host round trip on this path: an overflowing query reports QF_HASH_OVERFLOW in d_stats
+    run_search(a, nq, s, false, d_q);
+}
+
+void vdb_index::exact_knn(const float* q, size_t nq, size_t top_k, bool dev, vdb_scored_point* out, uint32_t* out_n, hipStream_t s) {
+    if (nq == 0) return;
+    std::lock_guard<std::mutex> lk(mu);
+    use_device();
+    if (!s) s = stream;
+    sync_device();
+    const uint32_t chunks = exact_knn_chunks((uint32_t)ids.size());
+    s_knn.reserve(nq * chunks * top_k, s, false);
+    if (dev) { launch_exact_knn(view(), q, (uint32_t)nq, (uint32_t)top_k, out, out_n, s_knn.p, chunks, s); return; }
+    s_q.reserve(nq * dim, s, false); s_out.reserve(nq * top_k, s, false); s_n.reserve(nq, s, false);
+    VDB_HIP(hipMemcpyAsync(s_q.p, q, nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
+    launch_exact_knn(view(), s_q.p, (uint32_t)nq, (uint32_t)top_k, s_out.p, s_n.p, s_knn.p, chunks, s);
+    VDB_HIP(hipMemcpyAsync(out, s_out.p, nq * top_k * sizeof(vdb_scored_point), hipMemcpyDeviceToHost, s));
+    VDB_HIP(hipMemcpyAsync(out_n, s_n.p, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    VDB_HIP(hipStreamSynchronize(s));
+}
+
+std::vector<float> vdb_index::score_rows(uint32_t query_slot, const std::vector<uint32_t>& slots) {
+    std::vector<float> raw(slots.size());
+    if (slots.empty()) return raw;
+    std::lock_guard<std::mutex> lk(mu);
+    use_device();
+    s_slots.reserve(slots.size(), stream, false); s_raw.reserve(slots.size(), stream, false);
+    VDB_HIP(hipMemcpyAsync(s_slots.p, slots.data(), slots.size() * 4, hipMemcpyHostToDevice, stream));
+    launch_score_rows(view(), query_slot, s_slots.p, (uint32_t)slots.size(), opts.arith, s_raw.p, stream);
+    VDB_HIP(hipMemcpyAsync(raw.data(), s_raw.p, raw.size() * 4, hipMemcpyDeviceToHost, stream));
+    VDB_HIP(hipStreamSynchronize(stream));
+    return raw;
+}
+
+std::vector<float> vdb_index::score_all_rows(uint32_t query_slot) {
+    const size_t n = ids.size();
+    std::vector<float> raw(n);
+    std::lock_guard<std::mutex> lk(mu);
+    use_device();
+    s_raw.reserve(n, stream, false); s_q.reserve(stride, stream, false);
+    // the query is a stored row: copy it out of the table (dense, dim floats) and stream the table past it
+    VDB_HIP(hipMemcpyAsync(s_q.p, d_vecs.p + (size_t)query_slot * stride, dim * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    launch_score_scan(s_q.p, 1, d_vecs.p, (uint32_t)n, (uint32_t)dim, stride, (int)metric, opts.arith, s_raw.p, stream);
+    VDB_HIP(hipMemcpyAsync(raw.data(), s_raw.p, n * 4, hipMemcpyDeviceToHost, stream));
+    VDB_HIP(hipStreamSynchronize(stream));
+    return raw;
+}
+
+// Layer-0 beam for a query that is a stored row (no second normalisation), greedy descent from
+// `entry_slot` first: the fallback search of hnsw.rs:268-273.  Returns the full sorted beam.
+std::vector<vdb_scored_point> vdb_index::search_from_row(uint32_t row_slot, uint32_t entry_slot, size_t ef_search) {
+    std::lock_guard<std::mutex> lk(mu);
+    use_device();
+    sync_device();
+    const uint32_t lvl = 0, off[2] = {0, 1};
+    s_slots.reserve(1, stream, false); s_lvl.reserve(1, stream, false); s_off.reserve(2, stream, false);
+    s_nb.reserve(m, stream, false); s_nbc.reserve(1, stream, false);
+    s_out.reserve(ef_search, stream, false); s_n.reserve(1, stream, false); s_stats.reserve(1, stream, false);
+    VDB_HIP(hipMemcpyAsync(s_slots.p, &row_slot, 4, hipMemcpyHostToDevice, stream));
+    VDB_HIP(hipMemcpyAsync(s_lvl.p, &lvl, 4, hipMemcpyHostToDevice, stream));
+    VDB_HIP(hipMemcpyAsync(s_off.p, off, 8, hipMemcpyHostToDevice, stream));
+    SearchArgs a{};
+    a.g = view(); a.mode = MODE_BUILD; a.arith = opts.arith; a.query_slots = s_slots.p; a.nq = 1;
+    a.entry = entry_slot; a.max_level = (uint32_t)current_max_level;
+    auto fl = first_live_slot(); a.fallback_live = fl ? *fl : NONE32;
+    a.ef = (uint32_t)ef_search; a.top_k = (uint32_t)ef_search; a.out = s_out.p; a.out_n = s_n.p; a.stats = s_stats.p;
+    a.q_levels = s_lvl.p; a.nb_off = s_off.p; a.m = (uint32_t)m; a.nb_out = s_nb.p; a.nb_cnt = s_nbc.p;
+    run_search(a, 1, stream, true, nullptr);
+    uint32_t n = 0;
+    std::vector<vdb_scored_point> out(ef_search);
+    VDB_HIP(hipMemcpyAsync(&n, s_n.p, 4, hipMemcpyDeviceToHost, stream));
+    VDB_HIP(hipMemcpyAsync(out.data(), s_out.p, ef_search * sizeof(vdb_scored_point), hipMemcpyDeviceToHost, stream));
+    VDB_HIP(hipStreamSynchronize(stream));
+    out.resize(n);
+    return out;
+}
+
+// greedy_search_layer_unfiltered as a public accessor (hnsw.rs:333-368).  Searches run the descent
+// inside the search kernel; this standalone form scores one adjacency list per step with the strict
+// scan kernel and applies the first-improvement rule on the host.
+uint32_t vdb_index::greedy_unfiltered(const float* q, uint32_t entry_slot, size_t level) {
+    std::vector<float> qn(q, q + dim);
+    std::lock_guard<std::mutex> lk(mu);
+    use_device();
+    sync_device();
+    s_q.reserve(stride, stream, false);
+    VDB_HIP(hipMemcpyAsync(s_q.p, qn.data(), dim * sizeof(float), hipMemcpyHostToDevice, stream));
+    uint32_t current = entry_slot; bool changed = true; int steps = 0;
+    auto score_list = [&](const std::vector<uint32_t>& slots) {
+        std::vector<float> raw(slots.size());
+        s_slots.reserve(slots.size(), stream, false); s_raw.reserve(slots.size(), stream, false);
+        // gather the rows and scan them against the query held in s_q
+        DevBuf<float> rows; rows.reserve(slots.size() * stride, stream, false);
+        for (size_t i = 0; i < slots.size(); ++i)
+            VDB_HIP(hipMemcpyAsync(rows.p + i * stride, d_vecs.p + (size_t)slots[i] * stride, stride * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        launch_score_scan(s_q.p, 1, rows.p, (uint32_t)slots.size(), (uint32_t)dim, stride, (int)metric, VDB_ARITH_STRICT, s_raw.p, stream);
+        VDB_HIP(hipMemcpyAsync(raw.data(), s_raw.p, raw.size() * 4, hipMemcpyDeviceToHost, stream));
+        VDB_HIP(hipStreamSynchronize(stream));
+        return raw;
+    };
+    while (changed && steps < 1000) {
+        ++steps; changed = false;
+        const std::vector<uint32_t>* nb = list(level, current);
+        if (!nb) continue;
+        std::vector<uint32_t> cand{current};
+        for (uint32_t x : *nb) if (!deleted[x]) cand.push_back(x);
+        if (cand.size() == 1) continue;
+        std::vector<float> raw = score_list(cand);
+        const float s_current = normalize_score(raw[0]);
+        for (size_t i = 1; i < cand.size(); ++i)
+            if (normalize_score(raw[i]) < s_current) { current = cand[i]; changed = true; break; }
+    }
+    return current;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Graph producer
+// ------------------------------------------------------------------------------------------------
+
+// One construction launch: for every new slot, greedy descent above its level and an ef-beam on
+// each layer from its level down to 0 (hnsw.rs:169-199); returns the first M results per layer.
+vdb_index::BuildResult vdb_index::build_search(const std::vector<uint32_t>& slots, uint32_t entry_slot) {
+    BuildResult br;
+    const size_t nq = slots.size();
+    br.off.resize(nq + 1); br.off[0] = 0;
+    std::vector<uint32_t> lv(nq);
+    for (size_t i = 0; i < nq; ++i) { lv[i] = levels[slots[i]]; br.off[i + 1] = br.off[i] + lv[i] + 1; }
+    const size_t rows = br.off[nq];
+    br.nb.assign(rows * m, 0); br.cnt.assign(rows, 0);
+    std::lock_guard<std::mutex> lk(mu);
+    use_device();
+    sync_device();
+    s_slots.reserve(nq, stream, false); s_lvl.reserve(nq, stream, false); s_off.reserve(nq + 1, stream, false);
+    s_nb.reserve(rows * m, stream, false); s_nbc.reserve(rows, stream, false);
+    s_n.reserve(nq, stream, false); s_stats.reserve(nq, stream, false);
+    VDB_HIP(hipMemcpyAsync(s_slots.p, slots.data(), nq * 4, hipMemcpyHostToDevice, stream));
+    VDB_HIP(hipMemcpyAsync(s_lvl.p, lv.data(), nq * 4, hipMemcpyHostToDevice, stream));
+    VDB_HIP(hipMemcpyAsync(s_off.p, br.off.data(), (nq + 1) * 4, hipMemcpyHostToDevice, stream));
+    VDB_HIP(hipMemsetAsync(s_nbc.p, 0, rows * 4, stream));
+    SearchArgs a{};
+    a.g = view(); a.mode = MODE_BUILD; a.arith = opts.arith; a.query_slots = s_slots.p; a.nq = (uint32_t)nq;
+    a.entry = entry_slot; a.max_level = (uint32_t)current_max_level;
+    auto fl = first_live_slot(); a.fallback_live = fl ? *fl : NONE32;
+    a.ef = (uint32_t)ef; a.top_k = 0; a.out = nullptr; a.out_n = s_n.p; a.stats = s_stats.p;
+    a.q_levels = s_lvl.p; a.nb_off = s_off.p; a.m = (uint32_t)m; a.nb_out = s_nb.p; a.nb_cnt = s_nbc.p;
+    run_search(a, nq, stream, true, nullptr);
+    VDB_HIP(hipMemcpyAsync(br.nb.data(), s_nb.p, rows * m * 4, hipMemcpyDeviceToHost, stream));
+    VDB_HIP(hipMemcpyAsync(br.cnt.data(), s_nbc.p, rows * 4, hipMemcpyDeviceToHost, stream));
+    VDB_HIP(hipStreamSynchronize(stream));
+    return br;
+}
+
+// hnsw.rs:175-205 for one point, given its per-layer candidate lists.
+void vdb_index::link_point(uint32_t s, const BuildResult& br, size_t qi) {
+    const size_t level = levels[s];
+    for (size_t l = level + 1; l-- > 0;) {
+        const size_t row = br.off[qi] + l;
+        std::vector<uint32_t> neighbors(br.nb.begin() + row * m, br.nb.begin() + row * m + br.cnt[row]);
+        std::vector<uint32_t> linked = neighbors;
+        if (std::find(linked.begin(), linked.end(), s) == linked.end()) linked.push_back(s);
+        list_or_default(l, s) = linked;
+        for (uint32_t nb : neighbors) {
+            std::vector<uint32_t>& e = list_or_default(l, nb);
+            if (std::find(e.begin(), e.end(), s) == e.end()) e.push_back(s);
+        }
+    }
+    if (level > current_max_level) { entry_point = ids[s]; current_max_level = level; }
+}
+
+void vdb_index::insert(uint64_t id, const float* v, size_t len) {
+    if (slot_of.count(id)) return;                                                   // hnsw.rs:122-125
+    if (len != dim) throw Failure(err_length_mismatch(dim, len));                    // hnsw.rs:127-133
+    const uint32_t s = append_rows(&id, v, 1);
+    if (!entry_point) { entry_point = id; current_max_level = levels[s]; return; }  // hnsw.rs:150-155
+    uint32_t ep = slot_of.at(*entry_point);
+    if (deleted[ep]) { auto f = first_live_slot(); if (f) ep = *f; }                 // hnsw.rs:158-164
+    BuildResult br = build_search({s}, ep);
+    link_point(s, br, 0);
+}
+
+// Extension: rounds of at most max(1, n_before / 4) points (capped) search the graph as it stood
+// at the start of their round, then link in order.
+void vdb_index::insert_batch(const uint64_t* pids, const float* v, size_t n, size_t len) {
+    if (len != dim) throw Failure(err_length_mismatch(dim, len));
+    size_t i = 0;
+    while (i < n) {
+        if (slot_of.count(pids[i])) { ++i; continue; }
+        if (!entry_point) { insert(pids[i], v + i * dim, len); ++i; continue; }
+        const size_t round = std::min<size_t>({n - i, std::max<size_t>(1, ids.size() / 4), 32768});
+        std::vector<uint64_t> rid; std::vector<float> rv; rid.reserve(round); rv.reserve(round * dim);
+        std::set<uint64_t> seen;
+        size_t j = i;
+        for (; j < n && rid.size() < round; ++j) {
+            if (slot_of.count(pids[j]) || !seen.insert(pids[j]).second) continue;
+            rid.push_back(pids[j]); rv.insert(rv.end(), v + j * dim, v + (j + 1) * dim);
+        }
+        i = j;
+        if (rid.empty()) continue;
+        uint32_t ep = slot_of.at(*entry_point);
+        if (deleted[ep]) { auto f = first_live_slot(); if (f) ep = *f; }
+        const uint32_t first = append_rows(rid.data(), rv.data(), rid.size());
+        std::vector<uint32_t> slots(rid.size());
+        for (size_t k = 0; k < rid.size(); ++k) slots[k] = first + (uint32_t)k;
+        BuildResult br = build_search(slots, ep);
+        for (size_t k = 0; k < slots.size(); ++k) link_point(slots[k], br, k);
+    }
+}
+
+void vdb_index::mark_deleted(uint64_t id) {                                          // hnsw.rs:111-117
+    auto it = slot_of.find(id);
+    if (it != slot_of.end() && !deleted[it->second]) { deleted[it->second] = 1; ++n_deleted; live.erase(id); deleted_dirty = true; }
+    if (entry_point && *entry_point == id) {
+        if (live.empty()) entry_point = std::nullopt; else entry_point = *live.begin();
+    }
+}
+
+void vdb_index::add_bidirectional_edge(size_t level, uint32_t a, uint32_t b) {       // hnsw.rs:328-331
+    list_or_default(level, a).push_back(b);
+    list_or_default(level, b).push_back(a);
+}
+
+void vdb_index::import_graph(size_t n, const uint64_t* pids, const uint32_t* lv, const float* vecs, const uint8_t* del,
+                             size_t n_layers, const vdb_layer_csr* csr, bool has_entry, uint64_t entry, size_t cur_max) {
+    use_device();
+    ids.clear(); slot_of.clear(); levels.clear(); hvecs.clear(); layers.clear(); deleted.clear(); live.clear();
+    n_deleted = 0; rows_on_device = 0;
+    ids.assign(pids, pids + n); hvecs.assign(vecs, vecs + n * dim);
+    levels.resize(n); deleted.assign(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+        slot_of[pids[i]] = (uint32_t)i; levels[i] = lv ? lv[i] : 0;
+        if (del && del[i]) { deleted[i] = 1; ++n_deleted; } else live.insert(pids[i]);
+    }
+    for (size_t l = 0; l < n_layers; ++l) {
+        if (layers.size() <= l) layers.resize(l + 1);
+        for (size_t k = 0; k < csr[l].n_lists; ++k) {
+            if (csr[l].owners[k] >= n) throw Failure(err_arg("list owner out of range"));
+            auto& lst = list_or_default(l, csr[l].owners[k]);
+            lst.assign(csr[l].neighbors + csr[l].offsets[k], csr[l].neighbors + csr[l].offsets[k + 1]);
+            for (uint32_t x : lst) if (x >= n) throw Failure(err_arg("neighbour slot out of range"));
+        }
+    }
+    if (has_entry) { if (!slot_of.count(entry)) throw Failure(err_arg("entry id unknown")); entry_point = entry; } else entry_point = std::nullopt;
+    current_max_level = cur_max;
+    // rows go to the device as given (already in stored form)
+    d_vecs.reserve(std::max<size_t>(n, 1) * stride, stream, false); d_ids.reserve(std::max<size_t>(n, 1), stream, false);
+    if (n) {
+        if (stride == dim) VDB_HIP(hipMemcpyAsync(d_vecs.p, vecs, n * dim * 4, hipMemcpyHostToDevice, stream));
+        else {
+            std::vector<float> padded(n * stride, 0.f);
+            for (size_t i = 0; i < n; ++i) std::memcpy(&padded[i * stride], vecs + i * dim, dim * 4);
+            VDB_HIP(hipMemcpyAsync(d_vecs.p, padded.data(), padded.size() * 4, hipMemcpyHostToDevice, stream));
+            VDB_HIP(hipStreamSynchronize(stream));
+        }
+        VDB_HIP(hipMemcpyAsync(d_ids.p, pids, n * 8, hipMemcpyHostToDevice, stream));
+        VDB_HIP(hipStreamSynchronize(stream));
+    }
+    rows_on_device = n; graph_dirty = true; deleted_dirty = true;
+}

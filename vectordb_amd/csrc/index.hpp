@@ -1,0 +1,142 @@
+// Host side of libvdbmi: the HNSW index (graph producer + device-resident search) and the segment
+// wrapper, mirroring src/vector/hnsw.rs and src/segment/segment.rs.
+#pragma once
+#include <memory>
+#include <mutex>
+#include <optional>
+#include <set>
+#include <unordered_map>
+#include <vector>
+
+#include "kernels.hpp"
+#include "payload.hpp"
+
+namespace vdb {
+
+// Device allocation that grows geometrically and keeps its contents.
+template <class T> struct DevBuf {
+    T* p = nullptr; size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    void reserve(size_t n, hipStream_t s, bool keep = true) {
+        if (n <= cap) return;
+        size_t ncap = std::max<size_t>(n, cap + cap / 2 + 64);
+        T* np = nullptr;
+        VDB_HIP(hipMalloc(&np, ncap * sizeof(T)));
+        if (p) {
+            if (keep && cap) VDB_HIP(hipMemcpyAsync(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice, s));
+            VDB_HIP(hipStreamSynchronize(s));
+            VDB_HIP(hipFree(p));
+        }
+        p = np; cap = ncap;
+    }
+};
+
+struct HostLayer {                       // layers[l]: HashMap<PointId, Vec<PointId>> of hnsw.rs:60, by slot
+    std::vector<int32_t> idx;            // slot -> list index, -1 = the slot owns no list here
+    std::vector<std::vector<uint32_t>> lists;
+    std::vector<uint32_t> owner;
+};
+
+struct FilterBits {                      // a Filter compiled against the segment's payloads
+    std::vector<uint32_t> pass, err;     // per slot; missing payload / Err -> pass = 0
+    DevBuf<uint32_t> d_pass, d_err;
+    size_t n_pass = 0, n_err = 0; uint64_t version = 0;
+};
+
+}  // namespace vdb
+
+struct vdb_index {
+    // configuration (hnsw.rs:59-73)
+    vdb_metric metric; size_t m, ef, max_level_cap, dim; double level_scale;
+    vdb_options opts; uint32_t stride;
+    // host mirror of the graph — the literal structures the reference keeps
+    std::vector<uint64_t> ids; std::unordered_map<uint64_t, uint32_t> slot_of;
+    std::vector<uint32_t> levels; std::vector<float> hvecs;     // n x dim, stored form
+    std::vector<vdb::HostLayer> layers;
+    std::vector<uint8_t> deleted; size_t n_deleted = 0; std::set<uint64_t> live;
+    std::optional<uint64_t> entry_point; size_t current_max_level = 0;
+    uint64_t level_draws = 0, sample_draws = 0;
+    // device state
+    hipStream_t stream = nullptr;
+    vdb::DevBuf<float> d_vecs; vdb::DevBuf<uint64_t> d_ids, d_desc0, d_udesc;
+    vdb::DevBuf<uint32_t> d_upper_base, d_pool, d_deleted; vdb::DevBuf<uint8_t> d_upper_cnt;
+    size_t rows_on_device = 0; bool graph_dirty = true, deleted_dirty = true;
+    size_t l0_edges = 0, upper_edges = 0, device_bytes = 0;
+    // per-call scratch (guarded by mu)
+    mutable std::mutex mu;
+    mutable vdb::DevBuf<float> s_q, s_raw; mutable vdb::DevBuf<vdb_scored_point> s_out, s_knn, s_cand;
+    mutable vdb::DevBuf<uint32_t> s_n, s_slots, s_lvl, s_off, s_nb, s_nbc, s_hash; mutable vdb::DevBuf<vdb_query_stats> s_stats;
+
+    vdb_index(vdb_metric metric, size_t m, size_t ef, size_t cap, size_t dim, const vdb_options& o);
+    ~vdb_index();
+
+    size_t len() const { return ids.size(); }
+    float normalize_score(float raw) const { return metric == VDB_DOT ? -raw : raw; }
+    const std::vector<uint32_t>* list(size_t level, uint32_t slot) const;
+    std::vector<uint32_t>& list_or_default(size_t level, uint32_t slot);
+    std::optional<uint32_t> first_live_slot() const;
+    void use_device() const;
+
+    // graph producer
+    void insert(uint64_t id, const float* v, size_t len);
+    void insert_batch(const uint64_t* pids, const float* v, size_t n, size_t len);
+    void mark_deleted(uint64_t id);
+    void add_bidirectional_edge(size_t level, uint32_t a, uint32_t b);
+    void import_graph(size_t n, const uint64_t* pids, const uint32_t* lv, const float* vecs, const uint8_t* del,
+                      size_t n_layers, const vdb_layer_csr* csr, bool has_entry, uint64_t entry, size_t cur_max);
+
+    // device
+    void sync_device();                                      // upload rows / packed graph / tombstones if stale
+    vdb::GraphView view() const;
+    struct FilterArgs { int mode = vdb::MODE_SEARCH; const vdb::FilterBits* bits = nullptr; uint32_t entry_slot = vdb::NONE32; };
+    void search_batch(const float* q, size_t nq, size_t top_k, size_t ef_search, const FilterArgs& fa,
+                      vdb_scored_point* out, uint32_t* out_n, vdb_query_stats* stats);
+    void search_batch_dev(const float* d_q, size_t nq, size_t top_k, size_t ef_search, vdb_scored_point* d_out, uint32_t* d_out_n,
+                          vdb_query_stats* d_stats, hipStream_t s);
+    void exact_knn(const float* q, size_t nq, size_t top_k, bool dev, vdb_scored_point* out, uint32_t* out_n, hipStream_t s);
+    std::vector<float> score_rows(uint32_t query_slot, const std::vector<uint32_t>& slots);
+    std::vector<float> score_all_rows(uint32_t query_slot);
+    std::vector<vdb_scored_point> search_from_row(uint32_t row_slot, uint32_t entry_slot, size_t ef_search);
+    uint32_t greedy_unfiltered(const float* q, uint32_t entry_slot, size_t level);
+    std::vector<float> maybe_normalize(const float* v);
+
+ private:
+    uint32_t append_rows(const uint64_t* pids, const float* v, size_t n);
+    size_t draw_level();
+    struct BuildResult { std::vector<uint32_t> off, nb, cnt; };
+    BuildResult build_search(const std::vector<uint32_t>& slots, uint32_t entry_slot);
+    void link_point(uint32_t slot, const BuildResult& br, size_t qi);
+    uint32_t pick_hash_log2(size_t ef, bool& global) const;
+    void run_search(vdb::SearchArgs a, size_t nq, hipStream_t s, bool retry_on_overflow, const float* d_q_all);
+};
+
+struct vdb_segment {
+    std::unique_ptr<vdb_index> hnsw; vdb_payload_index payload_index;
+    std::unordered_map<uint64_t, vdb_payload> payloads; std::set<uint64_t> deleted; uint64_t next_id = 1;   // segment.rs:21-29
+    uint64_t payload_version = 1;
+    mutable std::map<std::string, std::unique_ptr<vdb::FilterBits>> filter_cache;
+
+    explicit vdb_segment(vdb_index* h) : hnsw(h) {}
+    uint64_t insert(const float* v, size_t len, const vdb_payload* p);
+    void insert_batch(const float* v, size_t n, size_t len, const vdb_payload* const* p, uint64_t* out_ids);
+    const float* get_vector(uint64_t id) const;
+    void del(uint64_t id);
+    void purge();
+    size_t live_count() const { return hnsw->len() - deleted.size(); }
+    std::vector<vdb_scored_point> search(const float* q, size_t len, size_t top_k) const;
+    std::vector<vdb_scored_point> search_with_filter(const float* q, size_t len, size_t top_k, const vdb_filter* f) const;
+    std::vector<vdb_scored_point> post_filter(const float* q, size_t len, size_t top_k, const vdb_filter* f) const;
+    std::vector<vdb_scored_point> in_place_filtered_search(const float* q, size_t len, size_t top_k, const vdb_filter* f) const;
+    void search_batch(const float* q, size_t nq, size_t len, size_t top_k, size_t ef_search, const vdb_filter* f,
+                      vdb_scored_point* out, uint32_t* out_n) const;
+    const vdb::FilterBits& compile(const vdb_filter& f) const;
+    void build_filter_aware_edges(uint64_t id, const vdb_payload& p, const std::vector<std::string>& keys);
+
+ private:
+    void filtered_batch(const float* q, size_t nq, size_t len, size_t top_k, size_t ef_search, const vdb_filter* f,
+                        vdb_scored_point* out, uint32_t* out_n) const;
+    std::optional<uint64_t> find_entry_point_matching_filter(const vdb_filter& f) const;
+};

@@ -1,0 +1,78 @@
+// Host-visible launchers of the gfx950 kernels (definitions in kernels.hip).
+#pragma once
+#include "common.hpp"
+
+namespace vdb {
+
+constexpr uint32_t NONE32 = 0xFFFFFFFFu;
+constexpr uint32_t MAX_EF = 1024;          // result list lives in LDS: 8 B per entry
+constexpr uint32_t MAX_DIM = 2048;         // 64 lanes x 8 chunks x 4 floats
+
+// Packed adjacency descriptor: low 40 bits = first index into the neighbour pool, high 24 = degree.
+__host__ __device__ inline uint64_t make_desc(uint64_t off, uint32_t deg) { return off | ((uint64_t)deg << 40); }
+
+// Read-only view of the device-resident graph handed to every kernel.
+struct GraphView {
+    const float* vecs;          // n x stride floats, rows zero-padded to a multiple of 4
+    uint32_t stride, dim, n;
+    const uint64_t* ids;        // slot -> PointId
+    const uint64_t* desc0;      // layer 0 descriptor per slot
+    const uint32_t* upper_base; // per slot: first index into udesc, NONE32 when the slot owns no upper list
+    const uint8_t* upper_cnt;   // per slot: lists owned at layers 1..upper_cnt
+    const uint64_t* udesc;
+    const uint32_t* pool;       // neighbour slots, self-loops and duplicates removed
+    const uint32_t* deleted;    // bitmap (1 = tombstone) or nullptr when nothing is deleted
+    int metric;
+};
+
+enum SearchMode : int { MODE_SEARCH = 0, MODE_BUILD = 1, MODE_MASKED = 2, MODE_LITERAL = 3 };
+
+struct SearchArgs {
+    GraphView g;
+    int mode, arith;
+    const float* queries;        // nq x dim floats (MODE_BUILD: unused)
+    const uint32_t* query_slots; // MODE_BUILD: the stored row that acts as the query
+    uint32_t nq;
+    uint32_t entry, max_level;   // entry slot (NONE32: empty index)
+    uint32_t fallback_live;      // smallest-id live slot, used when the entry is tombstoned
+    uint32_t ef, top_k;
+    vdb_scored_point* out;       // nq x top_k
+    uint32_t* out_n;             // nq
+    vdb_query_stats* stats;      // nq or nullptr
+    uint32_t hash_log2;          // visited table capacity = 1 << hash_log2 entries
+    uint32_t* hash_global;       // nullptr: table in LDS; else nq x capacity words of scratch
+    // MODE_BUILD
+    const uint32_t* q_levels;    // node level per query
+    const uint32_t* nb_off;      // prefix sum of (level + 1) per query
+    uint32_t m;
+    uint32_t* nb_out;            // [(nb_off[q] + l) * m + j]
+    uint32_t* nb_cnt;            // [nb_off[q] + l]
+    // MODE_MASKED / MODE_LITERAL
+    const uint32_t* pass_bits;   // filter passes (errors count as false)
+    const uint32_t* err_bits;    // evaluate_filter returned Err
+    const uint32_t* q_entry;     // MODE_LITERAL: per-query entry (nullptr: args.entry)
+    vdb_scored_point* cand_scratch;   // MODE_LITERAL: nq x cand_cap candidate queue
+    uint32_t cand_cap;
+};
+
+// flags reported per query in vdb_query_stats.flags
+enum : uint32_t { QF_HASH_OVERFLOW = 1u, QF_FILTER_ERROR = 2u, QF_CAND_OVERFLOW = 4u };
+
+void launch_search(const SearchArgs& a, hipStream_t s);
+size_t search_lds_bytes(const SearchArgs& a);
+
+// out[q * n + i] = score(queries[q], base[i]); queries nq x dim (dense), base rows at `stride`.
+void launch_score_scan(const float* queries, uint32_t nq, const float* base, uint32_t n, uint32_t dim, uint32_t stride,
+                       int metric, int arith, float* out, hipStream_t s);
+// raw[i] = score(vecs[query_slot], vecs[slots[i]]) for i < n (stored rows on both sides).
+void launch_score_rows(const GraphView& g, uint32_t query_slot, const uint32_t* slots, uint32_t n, int arith, float* raw, hipStream_t s);
+// In-place row normalisation (hnsw.rs:752-764): rows first..first+n of `vecs`; zero-norm rows stay.
+void launch_normalize_rows(float* vecs, uint32_t stride, uint32_t dim, uint32_t first, uint32_t n, hipStream_t s);
+// Exact k-NN (strict arithmetic, (sort_key asc, id asc)) over live rows.
+void launch_exact_knn(const GraphView& g, const float* queries, uint32_t nq, uint32_t top_k, vdb_scored_point* out, uint32_t* out_n,
+                      vdb_scored_point* scratch, uint32_t n_chunks, hipStream_t s);
+uint32_t exact_knn_chunks(uint32_t n);
+void launch_topk_merge(const vdb_scored_point* lists, const uint32_t* counts, uint32_t n_shards, uint32_t nq, uint32_t k,
+                       vdb_scored_point* out, uint32_t* out_n, hipStream_t s);
+
+}  // namespace vdb

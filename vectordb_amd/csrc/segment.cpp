@@ -1,0 +1,343 @@
+// Segment (src/segment/segment.rs) over the device-resident index: id assignment, payload
+// bookkeeping, tombstones and purge on the host; every distance on the GPU.
+#include <cstring>
+
+#include "index.hpp"
+
+using namespace vdb;
+
+void vdb_filter::serialise(std::string& out) const {
+    auto put_value = [&](const vdb_value& v) {
+        out += char('a' + v.kind());
+        std::visit([&](const auto& x) {
+            using T = std::decay_t<decltype(x)>;
+            auto put_str = [&](const std::string& s) { out += std::to_string(s.size()); out += ':'; out += s; };
+            if constexpr (std::is_same_v<T, int64_t>) out += std::to_string(x);
+            else if constexpr (std::is_same_v<T, OF64>) { uint64_t b; double d = std::isnan(x.v) ? NAN : (x.v == 0 ? 0.0 : x.v); std::memcpy(&b, &d, 8); out += std::to_string(b); }
+            else if constexpr (std::is_same_v<T, std::string>) put_str(x);
+            else if constexpr (std::is_same_v<T, Bool8>) out += x.v ? '1' : '0';
+            else if constexpr (std::is_same_v<T, std::vector<int64_t>>) for (auto e : x) { out += std::to_string(e); out += ','; }
+            else if constexpr (std::is_same_v<T, std::vector<OF64>>) for (auto e : x) { uint64_t b; std::memcpy(&b, &e.v, 8); out += std::to_string(b); out += ','; }
+            else if constexpr (std::is_same_v<T, std::vector<std::string>>) for (auto& e : x) put_str(e);
+            else for (auto e : x) out += e.v ? '1' : '0';
+        }, v.d);
+        out += ';';
+    };
+    switch (kind) {
+        case Match: out += "M"; out += std::to_string(key.size()); out += ':'; out += key; put_value(value); break;
+        case Compare: out += "C"; out += char('0' + (int)op); out += std::to_string(key.size()); out += ':'; out += key; put_value(value); break;
+        case And: case Or: out += (kind == And ? "A(" : "O("); for (auto& k : kids) k.serialise(out); out += ')'; break;
+        default: out += "N("; kids.at(0).serialise(out); out += ')';
+    }
+}
+
+namespace {
+
+std::vector<vdb_scored_point> one_query(vdb_index& h, const float* q, size_t len, size_t top_k, const vdb_index::FilterArgs& fa) {
+    if (len != h.dim) throw Failure(err_length_mismatch(h.dim, len));              // hnsw.rs:519-524 / :593-598
+    std::vector<vdb_scored_point> out(std::max<size_t>(top_k, 1));
+    uint32_t n = 0;
+    h.search_batch(q, 1, top_k, 0, fa, out.data(), &n, nullptr);
+    out.resize(n);
+    return out;
+}
+
+// hnsw.rs:210-325 on index `h` with the given payload structures.
+void filter_aware_edges(vdb_index& h, const vdb_payload_index& pidx, const std::unordered_map<uint64_t, vdb_payload>& payloads,
+                        uint64_t point_id, const vdb_payload& payload, const std::vector<std::string>& keys) {
+    const uint32_t self = h.slot_of.at(point_id);
+    const size_t m = h.m;
+    std::set<uint64_t> extra;                                                      // DET-5
+    struct Scored { uint32_t slot; float raw; };
+    auto sort_raw = [&](std::vector<Scored>& v) {                                  // hnsw.rs:250-256 / :291-297 (stable)
+        if (h.metric == VDB_DOT) std::stable_sort(v.begin(), v.end(), [](const Scored& a, const Scored& b) { return a.raw > b.raw; });
+        else std::stable_sort(v.begin(), v.end(), [](const Scored& a, const Scored& b) { return a.raw < b.raw; });
+    };
+    for (const std::string& key : keys) {
+        const vdb_value* value = payload.get(key);
+        if (!value) continue;
+        if (const std::set<uint64_t>* id_set = pidx.query_exact(key, *value)) {
+            // reservoir sampling of <= 100 same-value points (rand 0.9 choose_multiple; DET-2)
+            std::vector<uint32_t> reservoir; size_t after = 0; const size_t amount = 100;
+            for (uint64_t pid : *id_set) {
+                if (pid == point_id) continue;
+                auto it = h.slot_of.find(pid);
+                if (it == h.slot_of.end() || h.deleted[it->second]) continue;
+                if (reservoir.size() < amount) { reservoir.push_back(it->second); continue; }
+                const uint64_t k = rng_draw(h.opts.seed, 2, h.sample_draws++) % (after + 1 + amount);
+                if (k < amount) reservoir[k] = it->second;
+                ++after;
+            }
+            std::vector<float> raw = h.score_rows(self, reservoir);
+            std::vector<Scored> scored;
+            for (size_t i = 0; i < reservoir.size(); ++i) scored.push_back({reservoir[i], raw[i]});
+            sort_raw(scored);
+            for (size_t i = 0; i < scored.size() && i < m; ++i) extra.insert(h.ids[scored[i].slot]);
+            if (extra.size() >= m) break;
+        }
+        std::vector<Scored> candidates;
+        if (h.current_max_level > 0) {                                              // hnsw.rs:268-273
+            // query = the stored row, no second normalisation: a build-mode launch at node level 0
+            std::vector<vdb_scored_point> res = h.search_from_row(self, h.slot_of.at(*h.entry_point), h.ef);
+            for (auto& sp : res) candidates.push_back({h.slot_of.at(sp.id), sp.raw_score});
+        } else {                                                                    // hnsw.rs:275-288 (DET-6)
+            std::vector<float> raw = h.score_all_rows(self);
+            for (uint64_t lid : h.live) {
+                if (lid == point_id) continue;
+                const uint32_t s = h.slot_of.at(lid);
+                candidates.push_back({s, raw[s]});
+            }
+        }
+        sort_raw(candidates);
+        size_t taken = 0;
+        for (const Scored& c : candidates) {
+            if (taken >= m) break;
+            auto pit = payloads.find(h.ids[c.slot]);
+            if (pit == payloads.end()) continue;
+            const vdb_value* v = pit->second.get(key);
+            if (!v || !(*v == *value)) continue;
+            extra.insert(h.ids[c.slot]); ++taken;
+        }
+        if (extra.size() >= m) break;
+    }
+    extra.insert(point_id);                                                         // hnsw.rs:318
+    for (uint64_t nid : extra) h.add_bidirectional_edge(0, self, h.slot_of.at(nid));
+}
+
+}  // namespace
+
+uint64_t vdb_segment::insert(const float* v, size_t len, const vdb_payload* p) {     // segment.rs:32-61
+    const uint64_t pid = next_id;
+    if (len != hnsw->dim) throw Failure(err_length_mismatch(hnsw->dim, len));
+    hnsw->insert(pid, v, len);
+    if (p) {
+        payload_index.insert(pid, *p);
+        payloads[pid] = *p;
+        ++payload_version;
+        const std::vector<std::string> keys = p->scalar_keys();
+        if (!keys.empty()) filter_aware_edges(*hnsw, payload_index, payloads, pid, *p, keys);
+    }
+    next_id += 1;
+    return pid;
+}
+
+// Extension: vectors go through vdb_index::insert_batch (rounds), then payload bookkeeping and the
+// filter-aware edges of each point run in id order against the finished graph.
+void vdb_segment::insert_batch(const float* v, size_t n, size_t len, const vdb_payload* const* p, uint64_t* out_ids) {
+    if (len != hnsw->dim) throw Failure(err_length_mismatch(hnsw->dim, len));
+    std::vector<uint64_t> pids(n);
+    for (size_t i = 0; i < n; ++i) pids[i] = next_id + i;
+    hnsw->insert_batch(pids.data(), v, n, len);
+    for (size_t i = 0; i < n; ++i) {
+        if (p && p[i]) {
+            payload_index.insert(pids[i], *p[i]);
+            payloads[pids[i]] = *p[i];
+        }
+    }
+    ++payload_version;
+    for (size_t i = 0; i < n; ++i) {
+        if (!(p && p[i])) continue;
+        const std::vector<std::string> keys = p[i]->scalar_keys();
+        if (!keys.empty()) filter_aware_edges(*hnsw, payload_index, payloads, pids[i], *p[i], keys);
+    }
+    next_id += n;
+    if (out_ids) std::memcpy(out_ids, pids.data(), n * sizeof(uint64_t));
+}
+
+const float* vdb_segment::get_vector(uint64_t id) const {                           // segment.rs:64-69
+    if (deleted.count(id)) return nullptr;
+    auto it = hnsw->slot_of.find(id);
+    if (it == hnsw->slot_of.end() || hnsw->deleted[it->second]) return nullptr;
+    return &hnsw->hvecs[(size_t)it->second * hnsw->dim];
+}
+
+void vdb_segment::del(uint64_t id) {                                                // segment.rs:71-99
+    if (deleted.count(id) || !hnsw->slot_of.count(id)) return;
+    auto pit = payloads.find(id);
+    if (pit != payloads.end()) payload_index.remove(id, pit->second);
+    deleted.insert(id);
+    hnsw->mark_deleted(id);
+    ++payload_version;
+    const size_t deleted_count = deleted.size(), total = hnsw->len();
+    if (deleted_count >= 100 && ((float)deleted_count / (float)total) >= 0.25f) purge();
+}
+
+void vdb_segment::purge() {                                                         // segment.rs:166-217
+    auto nh = std::make_unique<vdb_index>(hnsw->metric, hnsw->m, hnsw->ef, hnsw->max_level_cap, hnsw->dim, hnsw->opts);
+    nh->level_draws = hnsw->level_draws; nh->sample_draws = hnsw->sample_draws;      // the counter RNG continues
+    vdb_payload_index npi; std::unordered_map<uint64_t, vdb_payload> npl;
+    std::map<uint64_t, uint32_t> ordered(hnsw->slot_of.begin(), hnsw->slot_of.end());   // DET-6
+    for (auto& kv : ordered) {
+        const uint64_t id = kv.first;
+        if (deleted.count(id)) continue;
+        std::vector<float> vec(hnsw->hvecs.begin() + (size_t)kv.second * hnsw->dim, hnsw->hvecs.begin() + (size_t)(kv.second + 1) * hnsw->dim);
+        nh->insert(id, vec.data(), vec.size());
+        auto pit = payloads.find(id);
+        if (pit != payloads.end()) {
+            npi.insert(id, pit->second);
+            npl[id] = pit->second;
+            filter_aware_edges(*nh, npi, npl, id, pit->second, pit->second.scalar_keys());
+        }
+    }
+    hnsw = std::move(nh); payload_index = std::move(npi); payloads = std::move(npl);
+    deleted.clear();
+    filter_cache.clear();
+    ++payload_version;
+}
+
+std::vector<vdb_scored_point> vdb_segment::search(const float* q, size_t len, size_t top_k) const {   // segment.rs:103-119
+    if (live_count() == 0) throw Failure(err_search("No active points available to search."));
+    std::vector<vdb_scored_point> c = one_query(*hnsw, q, len, top_k * 2, {});
+    std::vector<vdb_scored_point> out;
+    for (auto& sp : c) { if (out.size() >= top_k) break; if (!deleted.count(sp.id)) out.push_back(sp); }
+    return out;
+}
+
+std::optional<uint64_t> vdb_segment::find_entry_point_matching_filter(const vdb_filter& f) const {     // hnsw.rs:558-583
+    switch (f.kind) {
+        case vdb_filter::Match: {
+            const std::set<uint64_t>* s = payload_index.query_exact(f.key, f.value);
+            if (!s) return std::nullopt;
+            for (uint64_t id : *s) {                                                // DET-4
+                auto it = hnsw->slot_of.find(id);
+                if (it != hnsw->slot_of.end() && !hnsw->deleted[it->second]) return id;
+            }
+            return std::nullopt;
+        }
+        case vdb_filter::And: case vdb_filter::Or:
+            for (auto& k : f.kids) if (auto r = find_entry_point_matching_filter(k)) return r;
+            return std::nullopt;
+        case vdb_filter::Not: return find_entry_point_matching_filter(f.kids.at(0));
+        default: return std::nullopt;
+    }
+}
+
+// Predicate -> per-slot bitmaps: pass (filter true) and err (evaluate_filter returned Err).  A slot
+// without a payload has neither bit (hnsw.rs:669 map_or(false), :391 continue).
+const FilterBits& vdb_segment::compile(const vdb_filter& f) const {
+    std::string key; f.serialise(key);
+    auto& slot = filter_cache[key];
+    const size_t n = hnsw->len();
+    if (slot && slot->version == payload_version && slot->pass.size() == (n + 31) / 32) return *slot;
+    if (!slot) slot = std::make_unique<FilterBits>();
+    FilterBits& fb = *slot;
+    fb.pass.assign((n + 31) / 32, 0); fb.err.assign((n + 31) / 32, 0); fb.n_pass = fb.n_err = 0;
+    for (size_t s = 0; s < n; ++s) {
+        auto pit = payloads.find(hnsw->ids[s]);
+        if (pit == payloads.end()) continue;
+        const Tri t = f.eval(pit->second);
+        if (t.s == Tri::True) { fb.pass[s >> 5] |= 1u << (s & 31); if (!hnsw->deleted[s]) ++fb.n_pass; }
+        else if (t.s == Tri::Err) { fb.err[s >> 5] |= 1u << (s & 31); if (!hnsw->deleted[s]) ++fb.n_err; }
+    }
+    hnsw->use_device();
+    const size_t w = std::max<size_t>(fb.pass.size(), 1);
+    fb.d_pass.reserve(w, hnsw->stream, false); fb.d_err.reserve(w, hnsw->stream, false);
+    if (!fb.pass.empty()) {
+        VDB_HIP(hipMemcpyAsync(fb.d_pass.p, fb.pass.data(), fb.pass.size() * 4, hipMemcpyHostToDevice, hnsw->stream));
+        VDB_HIP(hipMemcpyAsync(fb.d_err.p, fb.err.data(), fb.err.size() * 4, hipMemcpyHostToDevice, hnsw->stream));
+        VDB_HIP(hipStreamSynchronize(hnsw->stream));
+    }
+    fb.version = payload_version;
+    return fb;
+}
+
+void vdb_segment::filtered_batch(const float* q, size_t nq, size_t len, size_t top_k, size_t ef_search, const vdb_filter* f,
+                                 vdb_scored_point* out, uint32_t* out_n) const {
+    vdb_index& h = *hnsw;
+    if (len != h.dim) throw Failure(err_length_mismatch(h.dim, len));               // hnsw.rs:593-598
+    vdb_index::FilterArgs fa;
+    const FilterBits* bits = f ? &compile(*f) : nullptr;
+    fa.bits = bits;
+    if (h.opts.filter_mode == VDB_FILTER_MASKED) {
+        fa.mode = f ? MODE_MASKED : MODE_SEARCH;
+        h.search_batch(q, nq, top_k, ef_search, fa, out, out_n, nullptr);
+        return;
+    }
+    // ---- literal: entry selection on the host (hnsw.rs:600-626; no distances involved) ----
+    fa.mode = MODE_LITERAL;
+    if (h.entry_point) {
+        uint64_t id = *h.entry_point;
+        if (f) {
+            bool keep = false;
+            auto pit = payloads.find(id);
+            if (pit != payloads.end()) {
+                const Tri t = f->eval(pit->second);
+                if (t.s == Tri::Err) throw Failure(err_invalid_payload(t.msg));
+                keep = t.s == Tri::True;
+            }
+            if (!keep) { if (auto alt = find_entry_point_matching_filter(*f)) id = *alt; }
+        }
+        fa.entry_slot = h.slot_of.at(id);
+    } else {
+        std::optional<uint64_t> alt = f ? find_entry_point_matching_filter(*f) : std::nullopt;
+        if (!alt) { std::memset(out_n, 0, nq * sizeof(uint32_t)); return; }
+        fa.entry_slot = h.slot_of.at(*alt);
+    }
+    if (h.deleted[fa.entry_slot]) throw Failure(err_panic("called `Option::unwrap()` on a `None` value"));   // hnsw.rs:636
+    try {
+        h.search_batch(q, nq, top_k, ef_search, fa, out, out_n, nullptr);
+    } catch (const Failure& e) {
+        if (e.e.code == VDB_ERR_INVALID_PAYLOAD && e.e.msg.rfind("@slot:", 0) == 0 && f) {
+            const uint32_t s = (uint32_t)std::stoul(e.e.msg.substr(6));
+            auto pit = payloads.find(h.ids.at(s));
+            const Tri t = pit != payloads.end() ? f->eval(pit->second) : Tri::err("filter evaluation failed");
+            throw Failure(err_invalid_payload(t.msg));
+        }
+        throw;
+    }
+}
+
+std::vector<vdb_scored_point> vdb_segment::in_place_filtered_search(const float* q, size_t len, size_t top_k, const vdb_filter* f) const {
+    std::vector<vdb_scored_point> out(std::max<size_t>(top_k, 1));
+    uint32_t n = 0;
+    if (top_k == 0) return {};
+    filtered_batch(q, 1, len, top_k, 0, f, out.data(), &n);
+    out.resize(n);
+    return out;
+}
+
+std::vector<vdb_scored_point> vdb_segment::search_with_filter(const float* q, size_t len, size_t top_k, const vdb_filter* f) const {   // segment.rs:121-147
+    if (live_count() == 0) throw Failure(err_search("No active points available to search."));
+    std::vector<vdb_scored_point> c = in_place_filtered_search(q, len, top_k * 2, f);
+    std::vector<vdb_scored_point> out;
+    for (auto& sp : c) { if (out.size() >= top_k) break; if (!deleted.count(sp.id)) out.push_back(sp); }
+    return out;
+}
+
+std::vector<vdb_scored_point> vdb_segment::post_filter(const float* q, size_t len, size_t top_k, const vdb_filter* f) const {          // segment.rs:221-249
+    if (live_count() == 0) throw Failure(err_search("No active points available to search."));
+    std::vector<vdb_scored_point> c = one_query(*hnsw, q, len, top_k * 4, {});
+    std::vector<vdb_scored_point> out;
+    for (auto& sp : c) {
+        if (out.size() >= top_k) break;
+        if (deleted.count(sp.id)) continue;
+        if (f) {
+            auto pit = payloads.find(sp.id);
+            if (pit == payloads.end()) continue;
+            if (f->eval(pit->second).s != Tri::True) continue;                      // Err counts as false (segment.rs:241)
+        }
+        out.push_back(sp);
+    }
+    return out;
+}
+
+// Batched Segment::search / search_with_filter: over-fetch 2 x top_k, drop tombstones, keep top_k.
+void vdb_segment::search_batch(const float* q, size_t nq, size_t len, size_t top_k, size_t ef_search, const vdb_filter* f,
+                               vdb_scored_point* out, uint32_t* out_n) const {
+    if (live_count() == 0) throw Failure(err_search("No active points available to search."));
+    if (len != hnsw->dim) throw Failure(err_length_mismatch(hnsw->dim, len));
+    const size_t k2 = top_k * 2;
+    std::vector<vdb_scored_point> tmp(nq * std::max<size_t>(k2, 1)); std::vector<uint32_t> cnt(nq, 0);
+    if (k2) {
+        if (f) filtered_batch(q, nq, len, k2, ef_search, f, tmp.data(), cnt.data());
+        else hnsw->search_batch(q, nq, k2, ef_search, {}, tmp.data(), cnt.data(), nullptr);
+    }
+    for (size_t i = 0; i < nq; ++i) {
+        uint32_t n = 0;
+        for (uint32_t j = 0; j < cnt[i] && n < top_k; ++j) {
+            const vdb_scored_point& sp = tmp[i * k2 + j];
+            if (!deleted.count(sp.id)) out[i * top_k + n++] = sp;
+        }
+        out_n[i] = n;
+    }
+}
