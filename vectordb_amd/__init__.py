@@ -12,7 +12,7 @@ from .capi import (Arith, DBError, DistanceMetric, FilterMode, ListQueryKind,  #
                    ScalarComparisonOp, SCORED_DTYPE, STATS_DTYPE)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvdbmi.so")
+LIB_PATH = os.environ.get("VDB_LIBRARY") or os.path.join(_HERE, "csrc", "libvdbmi.so")   # VDB_LIBRARY: diagnostic builds
 _api = None
 
 

@@ -4,6 +4,7 @@
 #include "index.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 using namespace vdb;
@@ -122,24 +123,27 @@ void vdb_index::sync_device() {
     use_device();
     const size_t n = ids.size();
     if (graph_dirty) {
-        std::vector<uint64_t> desc0(n, make_desc(0, 0)), udesc;
-        std::vector<uint32_t> upper_base(n, NONE32), pool;
+        std::vector<uint32_t> adj0(n * ADJ_BLOCK, 0), ovf, pool, upper_base(n, NONE32);
+        std::vector<uint64_t> udesc;
         std::vector<uint8_t> upper_cnt(n, 0);
-        std::vector<uint32_t> stamp(n, 0); uint32_t epoch = 0;
-        auto pack = [&](const std::vector<uint32_t>& src, uint32_t self) -> uint64_t {
-            ++epoch;
-            const uint64_t off = pool.size();
-            for (uint32_t x : src) { if (x == self || stamp[x] == epoch) continue; stamp[x] = epoch; pool.push_back(x); }
-            return make_desc(off, (uint32_t)(pool.size() - off));
+        std::vector<uint32_t> stamp(n, 0), tmp; uint32_t epoch = 0;
+        auto clean = [&](const std::vector<uint32_t>& src, uint32_t self) {    // drop self loops and repeats, keep order
+            ++epoch; tmp.clear();
+            for (uint32_t x : src) { if (x == self || stamp[x] == epoch) continue; stamp[x] = epoch; tmp.push_back(x); }
         };
-        size_t reserve_edges = 0;
-        for (auto& L : layers) for (auto& l : L.lists) reserve_edges += l.size();
-        pool.reserve(reserve_edges);
         if (!layers.empty()) {
             const HostLayer& L0 = layers[0];
-            for (size_t k = 0; k < L0.lists.size(); ++k) desc0[L0.owner[k]] = pack(L0.lists[k], L0.owner[k]);
+            for (size_t k = 0; k < L0.lists.size(); ++k) {
+                const uint32_t s = L0.owner[k];
+                clean(L0.lists[k], s);
+                uint32_t* blk = &adj0[(size_t)s * ADJ_BLOCK];
+                blk[0] = (uint32_t)tmp.size();
+                const size_t inl = std::min<size_t>(tmp.size(), ADJ_INLINE);
+                std::copy(tmp.begin(), tmp.begin() + inl, blk + 1);
+                if (tmp.size() > ADJ_INLINE) { blk[63] = (uint32_t)ovf.size(); ovf.insert(ovf.end(), tmp.begin() + ADJ_INLINE, tmp.end()); }
+                l0_edges_acc += tmp.size();
+            }
         }
-        l0_edges = pool.size();
         // upper layers: a slot's descriptors for layers 1..cnt are consecutive in udesc
         for (size_t l = 1; l < layers.size(); ++l)
             for (uint32_t s : layers[l].owner) upper_cnt[s] = std::max<uint8_t>(upper_cnt[s], (uint8_t)std::min<size_t>(l, 255));
@@ -148,22 +152,27 @@ void vdb_index::sync_device() {
             upper_base[s] = (uint32_t)udesc.size();
             for (size_t l = 1; l <= upper_cnt[s]; ++l) {
                 const std::vector<uint32_t>* lst = list(l, s);
-                udesc.push_back(lst ? pack(*lst, s) : make_desc(0, 0));
+                if (!lst) { udesc.push_back(make_desc(0, 0)); continue; }
+                clean(*lst, s);
+                udesc.push_back(make_desc(pool.size(), (uint32_t)tmp.size()));
+                pool.insert(pool.end(), tmp.begin(), tmp.end());
             }
         }
-        upper_edges = pool.size() - l0_edges;
-        d_desc0.reserve(std::max<size_t>(n, 1), stream, false); d_upper_base.reserve(std::max<size_t>(n, 1), stream, false);
-        d_upper_cnt.reserve(std::max<size_t>(n, 1), stream, false);
+        l0_edges = l0_edges_acc; l0_edges_acc = 0; upper_edges = pool.size();
+        const size_t n1 = std::max<size_t>(n, 1);
+        d_adj0.reserve(n1 * ADJ_BLOCK, stream, false); d_ovf.reserve(std::max<size_t>(ovf.size(), 1), stream, false);
+        d_upper_base.reserve(n1, stream, false); d_upper_cnt.reserve(n1, stream, false);
         d_udesc.reserve(std::max<size_t>(udesc.size(), 1), stream, false); d_pool.reserve(std::max<size_t>(pool.size(), 1), stream, false);
         if (n) {
-            VDB_HIP(hipMemcpyAsync(d_desc0.p, desc0.data(), n * 8, hipMemcpyHostToDevice, stream));
+            VDB_HIP(hipMemcpyAsync(d_adj0.p, adj0.data(), adj0.size() * 4, hipMemcpyHostToDevice, stream));
             VDB_HIP(hipMemcpyAsync(d_upper_base.p, upper_base.data(), n * 4, hipMemcpyHostToDevice, stream));
             VDB_HIP(hipMemcpyAsync(d_upper_cnt.p, upper_cnt.data(), n, hipMemcpyHostToDevice, stream));
         }
+        if (!ovf.empty()) VDB_HIP(hipMemcpyAsync(d_ovf.p, ovf.data(), ovf.size() * 4, hipMemcpyHostToDevice, stream));
         if (!udesc.empty()) VDB_HIP(hipMemcpyAsync(d_udesc.p, udesc.data(), udesc.size() * 8, hipMemcpyHostToDevice, stream));
         if (!pool.empty()) VDB_HIP(hipMemcpyAsync(d_pool.p, pool.data(), pool.size() * 4, hipMemcpyHostToDevice, stream));
         VDB_HIP(hipStreamSynchronize(stream));
-        device_bytes = n * (size_t)stride * 4 + n * 8 + n * 8 + n * 5 + udesc.size() * 8 + pool.size() * 4;
+        device_bytes = n * (size_t)stride * 4 + n * 8 + adj0.size() * 4 + ovf.size() * 4 + n * 5 + udesc.size() * 8 + pool.size() * 4;
         graph_dirty = false;
     }
     if (deleted_dirty) {
@@ -181,32 +190,31 @@ void vdb_index::sync_device() {
 GraphView vdb_index::view() const {
     GraphView g{};
     g.vecs = d_vecs.p; g.stride = stride; g.dim = (uint32_t)dim; g.n = (uint32_t)ids.size();
-    g.ids = d_ids.p; g.desc0 = d_desc0.p; g.upper_base = d_upper_base.p; g.upper_cnt = d_upper_cnt.p;
+    g.ids = d_ids.p; g.adj0 = d_adj0.p; g.ovf = d_ovf.p; g.upper_base = d_upper_base.p; g.upper_cnt = d_upper_cnt.p;
     g.udesc = d_udesc.p; g.pool = d_pool.p; g.deleted = n_deleted ? d_deleted.p : nullptr; g.metric = (int)metric;
     return g;
 }
 
-uint32_t vdb_index::pick_hash_log2(size_t ef_, bool& global) const {
-    // visited nodes per query grow roughly linearly with ef; 48 slots per beam entry keeps the
-    // LDS table under 3/4 full on the graphs measured, larger beams use a table in HBM
-    size_t want = std::max<size_t>(1024, ef_ * 48);
-    uint32_t lg = 10;
-    while ((size_t(1) << lg) < want) ++lg;
-    global = lg > 13;
-    if (global) lg = std::max<uint32_t>(lg + 1, 16);
-    return lg;
+uint32_t vdb_index::pick_hash_log2(size_t, bool& global) const {
+    // 4096 ids (16 KiB of LDS) keep eight search wavefronts resident per CU; a query that visits
+    // more rows than that continues in a spill table in HBM (see Visited in kernels.hip)
+    global = false;
+    static const int forced = [] { const char* e = getenv("VDB_HASH_LOG2"); return e ? atoi(e) : 0; }();
+    return (forced >= 8 && forced <= 14) ? (uint32_t)forced : 12;
 }
 
-// Launches the search and, when the visited table overflowed for some queries, repeats those
-// with a larger table in HBM.
+// Launches the search.  Queries that outgrow the LDS visited table spill into HBM tables taken from
+// a pool; if the pool or a spill table is exhausted the query is flagged and (on the host-buffer
+// paths) repeated alone with a table sized for it.
 void vdb_index::run_search(SearchArgs a, size_t nq, hipStream_t s, bool retry_on_overflow, const float* d_q_all) {
     bool global = false;
     a.hash_log2 = pick_hash_log2(a.ef, global);
-    a.hash_global = nullptr;
-    if (global) {
-        s_hash.reserve(nq << a.hash_log2, s, false);
-        a.hash_global = s_hash.p;
-    }
+    // one spill table per possibly resident wavefront (256 CUs x 16), 2^15 ids each
+    a.spill_log2 = 15;
+    a.spill_tables = 4096;
+    s_spill.reserve((size_t)a.spill_tables + ((size_t)a.spill_tables << a.spill_log2), s, false);
+    a.spill_locks = s_spill.p; a.spill_pool = s_spill.p + a.spill_tables;
+    VDB_HIP(hipMemsetAsync(a.spill_locks, 0, (size_t)a.spill_tables * 4, s));
     launch_search(a, s);
     if (!retry_on_overflow) return;
     std::vector<vdb_query_stats> st(nq);
@@ -214,22 +222,21 @@ void vdb_index::run_search(SearchArgs a, size_t nq, hipStream_t s, bool retry_on
     VDB_HIP(hipStreamSynchronize(s));
     std::vector<uint32_t> redo;
     for (size_t i = 0; i < nq; ++i) if (st[i].flags & QF_HASH_OVERFLOW) redo.push_back((uint32_t)i);
-    uint32_t lg = std::max<uint32_t>(a.hash_log2 + 3, 16);
+    uint32_t lg = 19;
     while (!redo.empty()) {
-        if (lg > 26) throw Failure(err_device("visited table overflow beyond 2^26 entries"));
-        // one query at a time keeps the scratch table bounded
-        s_hash.reserve(size_t(1) << lg, s, false);
+        if (lg > 27) throw Failure(err_device("visited table overflow beyond 2^27 entries"));
+        // the query alone, with a private spill table sized for it
+        s_hash.reserve(64 + (size_t(1) << lg), s, false);
         for (uint32_t qi : redo) {
             SearchArgs b = a;
-            b.nq = 1; b.hash_log2 = lg; b.hash_global = s_hash.p;
+            b.nq = 1; b.spill_locks = s_hash.p; b.spill_pool = s_hash.p + 64; b.spill_tables = 1; b.spill_log2 = lg;
+            VDB_HIP(hipMemsetAsync(b.spill_locks, 0, 4, s));
             if (b.queries) b.queries = d_q_all + (size_t)qi * dim;
             if (b.query_slots) b.query_slots = a.query_slots + qi;
-            if (b.q_levels) { b.q_levels = a.q_levels + qi; b.nb_off = a.nb_off + qi; }
+            if (b.q_levels) { b.q_levels = a.q_levels + qi; b.nb_off = a.nb_off + qi; }   // nb_off values stay absolute
             if (b.q_entry) b.q_entry = a.q_entry + qi;
             if (b.cand_scratch) b.cand_scratch = a.cand_scratch + (size_t)qi * a.cand_cap;
             b.out = a.out ? a.out + (size_t)qi * a.top_k : nullptr; b.out_n = a.out_n + qi; b.stats = a.stats + qi;
-            // nb_off is absolute, so the single-query launch must not re-base it: handled by the
-            // kernel reading nb_off[q] with q == 0 at the shifted pointer.
             launch_search(b, s);
         }
         VDB_HIP(hipMemcpyAsync(st.data(), a.stats, nq * sizeof(vdb_query_stats), hipMemcpyDeviceToHost, s));

@@ -61,14 +61,14 @@ struct vdb_index {
     uint64_t level_draws = 0, sample_draws = 0;
     // device state
     hipStream_t stream = nullptr;
-    vdb::DevBuf<float> d_vecs; vdb::DevBuf<uint64_t> d_ids, d_desc0, d_udesc;
-    vdb::DevBuf<uint32_t> d_upper_base, d_pool, d_deleted; vdb::DevBuf<uint8_t> d_upper_cnt;
+    vdb::DevBuf<float> d_vecs; vdb::DevBuf<uint64_t> d_ids, d_udesc;
+    vdb::DevBuf<uint32_t> d_adj0, d_ovf, d_upper_base, d_pool, d_deleted; vdb::DevBuf<uint8_t> d_upper_cnt;
     size_t rows_on_device = 0; bool graph_dirty = true, deleted_dirty = true;
-    size_t l0_edges = 0, upper_edges = 0, device_bytes = 0;
+    size_t l0_edges = 0, upper_edges = 0, device_bytes = 0, l0_edges_acc = 0;
     // per-call scratch (guarded by mu)
     mutable std::mutex mu;
     mutable vdb::DevBuf<float> s_q, s_raw; mutable vdb::DevBuf<vdb_scored_point> s_out, s_knn, s_cand;
-    mutable vdb::DevBuf<uint32_t> s_n, s_slots, s_lvl, s_off, s_nb, s_nbc, s_hash; mutable vdb::DevBuf<vdb_query_stats> s_stats;
+    mutable vdb::DevBuf<uint32_t> s_n, s_slots, s_lvl, s_off, s_nb, s_nbc, s_hash, s_spill; mutable vdb::DevBuf<vdb_query_stats> s_stats;
 
     vdb_index(vdb_metric metric, size_t m, size_t ef, size_t cap, size_t dim, const vdb_options& o);
     ~vdb_index();

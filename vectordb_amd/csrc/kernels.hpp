@@ -8,6 +8,8 @@ constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 constexpr uint32_t MAX_EF = 1024;          // result list lives in LDS: 8 B per entry
 constexpr uint32_t MAX_DIM = 2048;         // 64 lanes x 8 chunks x 4 floats
 
+constexpr uint32_t ADJ_BLOCK = 64;         // dwords per layer-0 adjacency block
+constexpr uint32_t ADJ_INLINE = 62;        // neighbours held in the block itself
 // Packed adjacency descriptor: low 40 bits = first index into the neighbour pool, high 24 = degree.
 __host__ __device__ inline uint64_t make_desc(uint64_t off, uint32_t deg) { return off | ((uint64_t)deg << 40); }
 
@@ -16,11 +18,12 @@ struct GraphView {
     const float* vecs;          // n x stride floats, rows zero-padded to a multiple of 4
     uint32_t stride, dim, n;
     const uint64_t* ids;        // slot -> PointId
-    const uint64_t* desc0;      // layer 0 descriptor per slot
+    const uint32_t* adj0;       // layer 0: one 64-dword block per slot [degree, 62 neighbours, overflow start]
+    const uint32_t* ovf;        // layer 0: neighbours beyond the 62nd of high-degree nodes
     const uint32_t* upper_base; // per slot: first index into udesc, NONE32 when the slot owns no upper list
     const uint8_t* upper_cnt;   // per slot: lists owned at layers 1..upper_cnt
     const uint64_t* udesc;
-    const uint32_t* pool;       // neighbour slots, self-loops and duplicates removed
+    const uint32_t* pool;       // upper layers: neighbour slots (all lists: self-loops and duplicates removed)
     const uint32_t* deleted;    // bitmap (1 = tombstone) or nullptr when nothing is deleted
     int metric;
 };
@@ -39,8 +42,10 @@ struct SearchArgs {
     vdb_scored_point* out;       // nq x top_k
     uint32_t* out_n;             // nq
     vdb_query_stats* stats;      // nq or nullptr
-    uint32_t hash_log2;          // visited table capacity = 1 << hash_log2 entries
-    uint32_t* hash_global;       // nullptr: table in LDS; else nq x capacity words of scratch
+    uint32_t hash_log2;          // LDS visited table capacity = 1 << hash_log2 ids
+    uint32_t* spill_pool;        // spill tables in HBM for queries that outgrow the LDS table
+    uint32_t* spill_locks;       // one word per spill table: 0 free, 1 taken (zeroed before the launch)
+    uint32_t spill_tables, spill_log2;
     // MODE_BUILD
     const uint32_t* q_levels;    // node level per query
     const uint32_t* nb_off;      // prefix sum of (level + 1) per query

@@ -1,0 +1,460 @@
+// HNSW search on one wavefront per query: greedy descent over the upper layers (hnsw.rs:333-368),
+// then the ef-beam on one layer (hnsw.rs:420-511), plus the build-time, bitmap-masked and literal
+// filtered variants.  MODE, the lane-group shape (G lanes x CH 16-byte chunks per row, PASSES row
+// groups in flight), the arithmetic (STRICT) and optionally the metric are template parameters so
+// that each instantiation carries only its own code and scalar state.
+#pragma once
+#include "device_common.hpp"
+
+namespace vdb {
+namespace {
+
+#ifdef VDB_TIMING   // diagnostic build: per-phase shader-clock totals of the layer-0 beam
+#define VDB_T_MARK(i) do { const unsigned long long _t = clock64(); tacc[i] += _t - tlast; tlast = _t; } while (0)
+#else
+#define VDB_T_MARK(i) do { } while (0)
+#endif
+
+template <int MODE, int G, int CH, int PASSES, bool STRICT, int METRIC>
+struct Searcher {
+#ifdef VDB_TIMING
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+#endif
+    static constexpr int GG = G > 0 ? G : 8, CC = CH > 0 ? CH : 1, PP = PASSES > 0 ? PASSES : 1;
+    const SearchArgs& a;
+    const GraphView& gv;
+    float* qlds; uint32_t* cand; float* craw;
+    SortedList R, P;                      // R: beam / result list, P: filter-passing list (MODE_MASKED)
+    Visited vis;
+    QueryRegs<GG, CC> qr;
+    uint32_t rows_scored = 0, expanded = 0, adj_entries = 0, flags = 0, err_slot = 0, spill_idx = NONE32;
+
+    __device__ __forceinline__ Searcher(const SearchArgs& args) : a(args), gv(args.g) {}
+
+    __device__ __forceinline__ int metric() const { return METRIC >= 0 ? METRIC : gv.metric; }
+    __device__ __forceinline__ float key_of(float raw) const { return metric() == VDB_DOT ? -raw : raw; }    // hnsw.rs:103-108
+    __device__ __forceinline__ bool is_deleted(uint32_t s) const { return gv.deleted && bit_test(gv.deleted, s); }
+
+    __device__ __forceinline__ void reset_visited() {
+        const int lane = lane_id();
+        const uint4 empty4 = make_uint4(HASH_EMPTY, HASH_EMPTY, HASH_EMPTY, HASH_EMPTY);
+        for (uint32_t i = lane; i <= vis.mask; i += WAVE) reinterpret_cast<uint4*>(vis.tab)[i] = empty4;
+        vis.count = 0;
+        if (vis.spill) { for (uint32_t i = lane; i <= vis.smask; i += WAVE) reinterpret_cast<uint4*>(vis.spill)[i] = empty4; __threadfence_block(); }
+        vis.scount = 0;
+        wave_sync();
+    }
+    __device__ __forceinline__ void note_visited(uint32_t m) { if (vis.spill) vis.scount += m; else vis.count += m; }
+    // Called between neighbour chunks (all lanes): freezes the LDS table and takes a spill table
+    // from the pool when it is nearly full.  false = no room anywhere; the query is abandoned
+    // and flagged for the host.
+    __device__ __forceinline__ bool visited_room() {
+        if (!vis.spill) {
+            if (vis.count <= vis.limit) return true;
+            uint32_t idx = NONE32;
+            if (a.spill_pool) {
+                if (lane_id() == 0) {                  // any free table; a resident wave holds at most one
+                    uint32_t t = (blockIdx.x * 2654435761u) % a.spill_tables;
+                    for (uint32_t tries = 0; tries < a.spill_tables; ++tries) {
+                        if (atomicCAS(&a.spill_locks[t], 0u, 1u) == 0u) { idx = t; break; }
+                        t = (t + 1 == a.spill_tables) ? 0 : t + 1;
+                    }
+                }
+                idx = readlane_u(idx, 0);
+            }
+            if (idx == NONE32) { flags |= QF_HASH_OVERFLOW; return false; }
+            spill_idx = idx;
+            vis.spill = a.spill_pool + ((size_t)idx << a.spill_log2);
+            vis.smask = (1u << (a.spill_log2 - 2)) - 1; vis.sshift = 32 - (a.spill_log2 - 2);
+            vis.slimit = (1u << a.spill_log2) - (1u << a.spill_log2) / 4 - WAVE;
+            for (uint32_t i = lane_id(); i <= vis.smask; i += WAVE)
+                reinterpret_cast<uint4*>(vis.spill)[i] = make_uint4(HASH_EMPTY, HASH_EMPTY, HASH_EMPTY, HASH_EMPTY);
+            vis.scount = 0;
+            __threadfence_block();
+            wave_sync();
+            return true;
+        }
+        if (vis.scount > vis.slimit) { flags |= QF_HASH_OVERFLOW; return false; }
+        return true;
+    }
+
+    __device__ __forceinline__ void score(int m) {
+        if (STRICT) score_cands_strict(gv, qlds, cand, m, craw);
+        else score_cands_fast<GG, CC, PP, METRIC>(gv, qr, cand, m, craw);
+        wave_sync();
+        rows_scored += m;
+    }
+    __device__ __forceinline__ float score_one(uint32_t s) {
+        if (lane_id() == 0) cand[0] = s;
+        wave_sync();
+        score(1);
+        return craw[0];
+    }
+
+    // hnsw.rs:333-368: move to the FIRST neighbour that improves, rescan, at most 1000 steps.
+    __device__ __forceinline__ uint32_t greedy(uint32_t entry, uint32_t level) {
+        const int lane = lane_id();
+        uint32_t cur = entry;
+        float kcur = 0.f; bool have_cur = false;
+        bool changed = true; int steps = 0;
+        while (changed && steps < 1000) {
+            ++steps; changed = false;
+            const Adj A = open_adj(gv, level, cur);
+            if (A.deg == 0) continue;
+            ++expanded; adj_entries += A.deg;
+            const uint32_t nchunks = A.chunks();
+            for (uint32_t c = 0; c < nchunks && !changed; ++c) {
+                uint32_t nb;
+                const bool in = A.get(c, nb);
+                const bool ok = in && !is_deleted(nb);
+                const uint64_t mk = ballot(ok);
+                const int m = popc64(mk);
+                if (m == 0) continue;
+                if (!have_cur) { kcur = key_of(score_one(cur)); have_cur = true; }
+                if (ok) cand[popc64(mk & lanemask_lt(lane))] = nb;
+                wave_sync();
+                score(m);
+                const float kl = lane < m ? key_of(craw[lane]) : 0.f;
+                const uint64_t bm = ballot(lane < m && kl < kcur);
+                if (bm) {
+                    const int j = __ffsll((unsigned long long)bm) - 1;
+                    cur = cand[j]; kcur = readlane_f(kl, j); changed = true;
+                }
+                wave_sync();
+            }
+        }
+        return cur;
+    }
+
+    // hnsw.rs:370-418: scan the WHOLE list keeping the best filter-passing neighbour (strict <, so
+    // the first of equal minima wins), repeat until a scan makes no move; no step cap.  A
+    // neighbour whose filter evaluation is an Err aborts the search (hnsw.rs:392).
+    __device__ __forceinline__ uint32_t greedy_filtered(uint32_t entry, uint32_t level) {
+        const int lane = lane_id();
+        uint32_t cur = entry;
+        float kcur = 0.f; bool have_cur = false;
+        bool changed = true;
+        while (changed) {
+            changed = false;
+            const Adj A = open_adj(gv, level, cur);
+            if (A.deg == 0) break;
+            ++expanded; adj_entries += A.deg;
+            uint32_t best = cur;
+            const uint32_t nchunks = A.chunks();
+            for (uint32_t c = 0; c < nchunks; ++c) {
+                uint32_t nb;
+                const bool in = A.get(c, nb);
+                bool ok = in && !is_deleted(nb);
+                if (a.pass_bits) {
+                    const uint64_t em = ballot(ok && bit_test(a.err_bits, nb));
+                    if (em) { flags |= QF_FILTER_ERROR; err_slot = readlane_u(nb, __ffsll((unsigned long long)em) - 1); return cur; }
+                    ok = ok && bit_test(a.pass_bits, nb);
+                }
+                const uint64_t mk = ballot(ok);
+                const int m = popc64(mk);
+                if (m == 0) continue;
+                if (!have_cur) { kcur = key_of(score_one(cur)); have_cur = true; }
+                if (ok) cand[popc64(mk & lanemask_lt(lane))] = nb;
+                wave_sync();
+                score(m);
+                float bk = (lane < m) ? key_of(craw[lane]) : 0.f;
+                int bj = (lane < m && bk < kcur) ? lane : WAVE;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const float ok_ = __shfl_xor(bk, off); const int oj = __shfl_xor(bj, off);
+                    if (oj < WAVE && (bj == WAVE || ok_ < bk || (ok_ == bk && oj < bj))) { bk = ok_; bj = oj; }
+                }
+                if (bj < WAVE) { best = cand[bj]; kcur = bk; changed = true; }
+                wave_sync();
+            }
+            cur = best;
+        }
+        return cur;
+    }
+
+    // hnsw.rs:420-511 on `level`, starting from `entry`.  On return R holds the results sorted.
+    // MASKED additionally keeps the ef best filter-passing nodes in P.  FUSED: layer 0.
+    template <bool MASKED, bool FUSED> __device__ __forceinline__ void beam(uint32_t entry, uint32_t level, uint32_t ef) {
+        const int lane = lane_id();
+        reset_visited();
+        R.n = 0; R.cap = ef;
+        if (MASKED) { P.n = 0; P.cap = ef; }
+        wave_sync();
+        uint32_t start = entry;
+        if (is_deleted(entry) && a.fallback_live != NONE32) start = a.fallback_live;      // hnsw.rs:440-444
+        const float raw0 = score_one(start);
+        R.insert(key_of(raw0), start);
+        if (lane == 0) vis.insert(start);
+        note_visited(1);
+        if (MASKED && !is_deleted(start) && (!a.pass_bits || bit_test(a.pass_bits, start))) P.insert(key_of(raw0), start);
+        wave_sync();
+        // The adjacency block of the runner-up is requested while the current node is processed:
+        // after the merge it usually is the next node to expand and its neighbours are already
+        // in registers (one dependent memory round trip per expansion instead of two).
+        uint32_t pf_slot = NONE32, pf_word = 0;
+        uint32_t scan_from = 0;               // every entry before this chunk start is expanded
+#ifdef VDB_TIMING
+        tlast = clock64();
+#endif
+        for (;;) {
+            // best unexpanded entry of R == the candidate queue's minimum (evicted candidates can
+            // only re-surface on an exact key tie); also note the second best
+            int sel = -1;
+            uint32_t cur = 0, cur2 = NONE32;
+            for (uint32_t b = scan_from; b < R.n && cur2 == NONE32; b += WAVE) {
+                const uint32_t i = b + lane;
+                const uint32_t v = (i < R.n) ? R.val[i] : FLAG_EXPANDED;
+                uint64_t um = ballot(!(v & FLAG_EXPANDED));
+                if (um && sel < 0) { const int l = __ffsll((unsigned long long)um) - 1; sel = (int)b + l; cur = readlane_u(v, l); um &= um - 1; }
+                if (um && sel >= 0) cur2 = readlane_u(v, __ffsll((unsigned long long)um) - 1);
+            }
+            if (sel < 0) break;
+            scan_from = (uint32_t)sel & ~63u;
+            if (lane == 0) R.val[sel] = cur | FLAG_EXPANDED;
+            wave_sync();
+            VDB_T_MARK(0);
+            Adj A;
+            if (FUSED) {
+                const uint32_t w = (cur == pf_slot) ? pf_word : load_adj_word(gv, cur);
+                A = open_adj0(gv, w);
+                pf_slot = NONE32;
+            } else A = open_adj(gv, level, cur);
+            VDB_T_MARK(1);
+            if (A.deg == 0) continue;
+            ++expanded; adj_entries += A.deg;
+            const uint32_t nchunks = A.chunks();
+            uint32_t lowest = NONE32;          // smallest list position any candidate of this expansion took
+            for (uint32_t c = 0; c < nchunks; ++c) {
+                uint32_t nb;
+                const bool in = A.get(c, nb);
+                bool fresh = in && !is_deleted(nb);                           // hnsw.rs:475
+                if (fresh) fresh = vis.insert(nb);
+                const uint64_t mk = ballot(fresh);
+                const int m = popc64(mk);
+                VDB_T_MARK(2);
+                if (m == 0) continue;
+                note_visited(m);
+                if (fresh) cand[popc64(mk & lanemask_lt(lane))] = nb;
+                wave_sync();
+                // request the runner-up's block right before the row gather: the two fly together
+                // (issued any earlier, the wait for this node's own block would also wait for it)
+                if (FUSED && cur2 != NONE32 && pf_slot == NONE32) { pf_slot = cur2; pf_word = load_adj_word(gv, cur2); }
+                score(m);
+                VDB_T_MARK(3);
+                const float kj = (lane < m) ? key_of(craw[lane]) : 0.f;
+                const uint32_t sj = (lane < m) ? cand[lane] : 0u;
+                if (MASKED) P.offer(lane < m && (!a.pass_bits || bit_test(a.pass_bits, sj)), kj, sj);
+                const uint32_t lo = R.offer(lane < m, kj, sj);                // hnsw.rs:486-499, in list order
+                lowest = lo < lowest ? lo : lowest;
+                VDB_T_MARK(4);
+                if (!visited_room()) return;
+                VDB_T_MARK(5);
+            }
+            if (lowest != NONE32 && (lowest & ~63u) < scan_from) scan_from = lowest & ~63u;
+            if (FUSED && cur2 != NONE32 && pf_slot == NONE32) { pf_slot = cur2; pf_word = load_adj_word(gv, cur2); }   // nothing new was scored
+        }
+    }
+
+    // hnsw.rs:585-689 as written.  C is an unsorted array in global scratch; R (inverted order in
+    // the reference) keeps the ef LARGEST keys among entry + passing nodes and `bound` is its
+    // smallest key; output is descending by key.
+    __device__ __forceinline__ void literal_filtered(uint32_t q, uint32_t entry) {
+        const int lane = lane_id();
+        vdb_scored_point* C = a.cand_scratch + (size_t)q * a.cand_cap;
+        uint32_t cn = 0;
+        reset_visited();
+        R.n = 0; R.cap = a.ef;           // stored ascending by NEGATED key => position 0 is the largest key
+        wave_sync();
+        const float raw0 = score_one(entry);
+        const float key0 = key_of(raw0);
+        if (lane == 0) { C[0].id = entry; C[0].raw_score = raw0; C[0].sort_key = key0; vis.insert(entry); }
+        cn = 1; note_visited(1);
+        R.insert(-key0, entry);                                            // hnsw.rs:641-644: entry admitted unfiltered
+        float bound = key0;                                                // hnsw.rs:646
+        __threadfence_block();
+        wave_sync();
+        for (;;) {
+            if (cn == 0) break;
+            // pop the minimum of C (hnsw.rs:648); ties: lowest position
+            float bk = 0.f; uint32_t bi = NONE32;
+            for (uint32_t b = 0; b < cn; b += WAVE) {
+                const uint32_t i = b + lane;
+                if (i < cn) { float k = C[i].sort_key; if (bi == NONE32 || k < bk) { bk = k; bi = i; } }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float ok_ = __shfl_xor(bk, off); const uint32_t oi = (uint32_t)__shfl_xor((int)bi, off);
+                if (oi != NONE32 && (bi == NONE32 || ok_ < bk || (ok_ == bk && oi < bi))) { bk = ok_; bi = oi; }
+            }
+            const uint32_t cur = (uint32_t)C[bi].id;
+            wave_sync();
+            if (lane == 0) C[bi] = C[cn - 1];
+            --cn;
+            __threadfence_block();
+            wave_sync();
+            if (bk > bound) break;                                         // hnsw.rs:649-651
+            const Adj A = open_adj(gv, 0, cur);
+            if (A.deg == 0) continue;
+            ++expanded; adj_entries += A.deg;
+            const uint32_t nchunks = A.chunks();
+            for (uint32_t c = 0; c < nchunks; ++c) {
+                uint32_t nb;
+                const bool in = A.get(c, nb);
+                bool fresh = in && !is_deleted(nb);
+                if (fresh) fresh = vis.insert(nb);
+                const uint64_t mk = ballot(fresh);
+                const int m = popc64(mk);
+                if (m == 0) continue;
+                note_visited(m);
+                if (fresh) cand[popc64(mk & lanemask_lt(lane))] = nb;
+                wave_sync();
+                score(m);
+                if (cn + m > a.cand_cap) { flags |= QF_CAND_OVERFLOW; return; }
+                const float rj = (lane < m) ? craw[lane] : 0.f;
+                const float kj = key_of(rj);
+                const uint32_t sj = (lane < m) ? cand[lane] : 0u;
+                if (lane < m) { C[cn + lane].id = sj; C[cn + lane].raw_score = rj; C[cn + lane].sort_key = kj; }   // hnsw.rs:666
+                cn += m;
+                uint64_t pm = ballot(lane < m && a.pass_bits && bit_test(a.pass_bits, sj));
+                if (!a.pass_bits) pm = ballot(lane < m);
+                while (pm) {                                               // hnsw.rs:673-681, in list order
+                    const int j = __ffsll((unsigned long long)pm) - 1; pm &= pm - 1;
+                    const float k = readlane_f(kj, j);
+                    // push, then drop the SMALLEST key when over ef (inverted heap)
+                    // (the list is ascending in -key, so its last element holds the smallest key)
+                    if (R.n >= R.cap && !(-k < R.key[R.cap - 1])) {
+                        bound = -R.key[R.cap - 1];                          // pushed and popped again at once
+                        continue;
+                    }
+                    R.insert(-k, readlane_u(sj, j));
+                    bound = -R.key[R.n - 1];                                // peek(): smallest key kept
+                }
+                __threadfence_block();
+                wave_sync();
+                if (!visited_room()) return;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void emit(uint32_t q, const SortedList& L, bool negated) {
+        const int lane = lane_id();
+        const uint32_t n = L.n < a.top_k ? L.n : a.top_k;
+        for (uint32_t i = lane; i < n; i += WAVE) {
+            const uint32_t s = L.val[i] & ~FLAG_EXPANDED;
+            const float k = negated ? -L.key[i] : L.key[i];
+            vdb_scored_point sp; sp.id = gv.ids[s]; sp.sort_key = k; sp.raw_score = (metric() == VDB_DOT) ? -k : k;
+            a.out[(size_t)q * a.top_k + i] = sp;
+        }
+        if (lane == 0) a.out_n[q] = n;
+    }
+
+    __device__ __forceinline__ void run(uint32_t q, char* smem) {
+        const int lane = lane_id();
+        // ---- carve LDS (every offset a multiple of 16 bytes) ----
+        const uint32_t ef_cap = (a.ef + 63u) & ~63u;
+        size_t off = 0;
+        R.key = reinterpret_cast<float*>(smem + off); off += ef_cap * 4;
+        R.val = reinterpret_cast<uint32_t*>(smem + off); off += ef_cap * 4;
+        R.key2 = reinterpret_cast<float*>(smem + off); off += ef_cap * 4;
+        R.val2 = reinterpret_cast<uint32_t*>(smem + off); off += ef_cap * 4;
+        if (MODE == MODE_MASKED) {
+            P.key = reinterpret_cast<float*>(smem + off); off += ef_cap * 4;
+            P.val = reinterpret_cast<uint32_t*>(smem + off); off += ef_cap * 4;
+            P.key2 = reinterpret_cast<float*>(smem + off); off += ef_cap * 4;
+            P.val2 = reinterpret_cast<uint32_t*>(smem + off); off += ef_cap * 4;
+        }
+        cand = reinterpret_cast<uint32_t*>(smem + off); off += WAVE * 4;
+        craw = reinterpret_cast<float*>(smem + off); off += WAVE * 4;
+        qlds = reinterpret_cast<float*>(smem + off); off += (size_t)gv.stride * 4;
+        vis.mask = (1u << (a.hash_log2 - 2)) - 1; vis.shift = 32 - (a.hash_log2 - 2);
+        vis.limit = (1u << a.hash_log2) - (1u << a.hash_log2) / 4 - WAVE;
+        vis.tab = reinterpret_cast<uint32_t*>(smem + off);
+        vis.spill = nullptr; vis.smask = 0; vis.sshift = 0; vis.scount = 0; vis.slimit = 0; vis.count = 0;
+
+        if (lane == 0) a.out_n[q] = 0;
+        if (a.entry == NONE32) return;                                     // hnsw.rs:515-518
+#ifdef VDB_TIMING
+        const unsigned long long t_begin = wall_clock64();
+#endif
+
+        // ---- query -> LDS (normalised for Cosine: hnsw.rs:526-536, 752-764) ----
+        const float* qsrc = (MODE == MODE_BUILD) ? gv.vecs + (size_t)a.query_slots[q] * gv.stride : a.queries + (size_t)q * gv.dim;
+        for (uint32_t i = lane; i < gv.stride; i += WAVE) qlds[i] = (i < gv.dim) ? qsrc[i] : 0.f;
+        wave_sync();
+        if (metric() == VDB_COSINE && MODE != MODE_BUILD && MODE != MODE_LITERAL) {
+            float s = -0.0f;                                               // every lane runs the same sequential sum
+            for (uint32_t i = 0; i < gv.dim; ++i) { float p = qlds[i] * qlds[i]; s = s + p; }
+            const float norm = __builtin_sqrtf(s);
+            wave_sync();
+            if (norm != 0.0f) for (uint32_t i = lane; i < gv.dim; i += WAVE) qlds[i] = qlds[i] / norm;
+            wave_sync();
+        }
+        if (!STRICT) qr.load(qlds, gv.stride, metric());
+
+        if (MODE == MODE_LITERAL) {
+            uint32_t cur = a.q_entry ? a.q_entry[q] : a.entry;
+            for (uint32_t l = a.max_level; l >= 1 && !(flags & QF_FILTER_ERROR); --l) cur = greedy_filtered(cur, l);   // hnsw.rs:628-630
+            if (!(flags & QF_FILTER_ERROR)) literal_filtered(q, cur);
+            if (!(flags & (QF_HASH_OVERFLOW | QF_CAND_OVERFLOW | QF_FILTER_ERROR))) emit(q, R, true);
+        } else if (MODE == MODE_BUILD) {
+            const uint32_t lvl = a.q_levels[q];
+            uint32_t cur = a.entry;
+            for (uint32_t l = a.max_level; l > lvl; --l) cur = greedy(cur, l);          // hnsw.rs:169-173
+            for (int l = (int)lvl; l >= 0; --l) {                                       // hnsw.rs:175-199
+                if (l == 0) beam<false, true>(cur, 0, a.ef); else beam<false, false>(cur, (uint32_t)l, a.ef);
+                if (flags & QF_HASH_OVERFLOW) break;
+                const uint32_t cnt = R.n < a.m ? R.n : a.m;
+                const size_t row = (size_t)a.nb_off[q] + (uint32_t)l;
+                for (uint32_t i = lane; i < cnt; i += WAVE) a.nb_out[row * a.m + i] = R.val[i] & ~FLAG_EXPANDED;
+                if (lane == 0) a.nb_cnt[row] = cnt;
+                if (R.n > 0) cur = R.val[0] & ~FLAG_EXPANDED;
+                wave_sync();
+            }
+            if (a.out && !(flags & QF_HASH_OVERFLOW)) emit(q, R, false);                // layer-0 beam, full list
+        } else {
+            uint32_t cur = a.entry;
+            for (uint32_t l = a.max_level; l >= 1; --l) cur = greedy(cur, l);           // hnsw.rs:538-541
+            if (MODE == MODE_MASKED) { beam<true, true>(cur, 0, a.ef); if (!(flags & QF_HASH_OVERFLOW)) emit(q, P, false); }
+            else { beam<false, true>(cur, 0, a.ef); if (!(flags & QF_HASH_OVERFLOW)) emit(q, R, false); }
+        }
+        if (spill_idx != NONE32) {                                          // hand the spill table back
+            __threadfence();
+            if (lane == 0) atomicExch(&a.spill_locks[spill_idx], 0u);
+        }
+#ifdef VDB_TIMING
+        // diagnostic build only: adj_entries carries the wavefront's lifetime in 10 ns ticks, rows_scored its start tick
+        adj_entries = (uint32_t)(wall_clock64() - t_begin); rows_scored = (uint32_t)t_begin;
+        if (lane == 0 && a.out && a.top_k >= 4) {      // phase totals overwrite this query's result records
+            unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.out + (size_t)q * a.top_k);
+            for (int i = 0; i < 6; ++i) dbg[i] = tacc[i];
+        }
+#endif
+        // on a filter error `expanded` carries the slot whose evaluation failed
+        if (a.stats && lane == 0) a.stats[q] = {rows_scored, (flags & QF_FILTER_ERROR) ? err_slot : expanded, adj_entries, flags};
+    }
+};
+
+template <int MODE, int G, int CH, int PASSES, bool STRICT, int METRIC>
+__global__ void __launch_bounds__(64) search_kernel(SearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Searcher<MODE, G, CH, PASSES, STRICT, METRIC> s(a);
+    s.run(blockIdx.x, smem);
+}
+
+// FAST shapes: rows up to 128 floats use 8 lanes x 4 chunks (8 rows per wave instruction, 32 rows
+// in flight), up to 1024 floats the whole wave per row x 4 chunks, up to 2048 floats x 8 chunks.
+template <int MODE, int METRIC>
+void launch_search_fast(const SearchArgs& a, size_t lds, hipStream_t st) {
+    const uint32_t chunks = a.g.stride / 4;
+    if (chunks <= 32) hipLaunchKernelGGL((search_kernel<MODE, 8, 4, 4, false, METRIC>), dim3(a.nq), dim3(64), lds, st, a);
+    else if (chunks <= 256) hipLaunchKernelGGL((search_kernel<MODE, 64, 4, 8, false, METRIC>), dim3(a.nq), dim3(64), lds, st, a);
+    else if (chunks <= 512) hipLaunchKernelGGL((search_kernel<MODE, 64, 8, 4, false, METRIC>), dim3(a.nq), dim3(64), lds, st, a);
+    else throw Failure(err_arg("dimension above 2048 is not supported"));
+}
+template <int MODE>
+void launch_search_strict(const SearchArgs& a, size_t lds, hipStream_t st) {
+    hipLaunchKernelGGL((search_kernel<MODE, 0, 0, 0, true, -1>), dim3(a.nq), dim3(64), lds, st, a);
+}
+
+}  // namespace
+}  // namespace vdb
