@@ -31,3 +31,7 @@ print("phase shares of beam cycles (mean over queries):")
 for i, nm in enumerate(names):
     print(f"  {nm:14s} {100*ph[:, i].sum()/tot.sum():5.1f}%   cycles/expansion {ph[:, i].sum()/st['expanded'].sum():7.0f}")
 print(f"  beam cycles per expansion {tot.sum()/st['expanded'].sum():.0f}; implied clock {tot.mean()/life.mean():.0f} MHz-equivalent (cycles per us of lifetime)")
+rs = st_rows = None
+out2, cnt2, st2 = h.search_batch(q[:1], k, ef_search=ef, with_stats=True)
+big = np.argsort(-life)[:8]
+print("slowest queries: lifetime us / expansions:", [(int(life[i]), int(st['expanded'][i])) for i in big])

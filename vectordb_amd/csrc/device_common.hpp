@@ -338,7 +338,14 @@ struct Visited {
         const uint32_t hv = s * 2654435761u;
         if (!spill) return probe<false, false>(tab, mask, hv >> shift, s) == 1;
         if (probe<true, false>(tab, mask, hv >> shift, s) == 0) return false;
-        return probe<false, true>(spill, smask, hv >> sshift, s) == 1;
+        // HBM table: one CAS on the id's preferred slot of its bucket settles almost every lookup in
+        // a single round trip (slots are never emptied, so an id stored elsewhere in the probe
+        // sequence implies its preferred slot is taken and the CAS cannot report EMPTY for it).
+        const uint32_t b = hv >> sshift;
+        const uint32_t old = atomicCAS(&spill[4 * b + ((hv >> 4) & 3u)], HASH_EMPTY, s);
+        if (old == HASH_EMPTY) return true;
+        if (old == s) return false;
+        return probe<false, true>(spill, smask, b, s) == 1;
     }
 };
 

@@ -212,9 +212,15 @@ void vdb_index::run_search(SearchArgs a, size_t nq, hipStream_t s, bool retry_on
     // one spill table per possibly resident wavefront (256 CUs x 16), 2^15 ids each
     a.spill_log2 = 15;
     a.spill_tables = 4096;
-    s_spill.reserve((size_t)a.spill_tables + ((size_t)a.spill_tables << a.spill_log2), s, false);
+    const size_t spill_words = (size_t)a.spill_tables + ((size_t)a.spill_tables << a.spill_log2);
+    if (s_spill.cap < spill_words) {
+        // lock words start free and every query hands its table back, so they are cleared once:
+        // launches on different streams may share the pool while they overlap
+        s_spill.reserve(spill_words, s, false);
+        VDB_HIP(hipMemsetAsync(s_spill.p, 0, (size_t)a.spill_tables * 4, s));
+        VDB_HIP(hipStreamSynchronize(s));
+    }
     a.spill_locks = s_spill.p; a.spill_pool = s_spill.p + a.spill_tables;
-    VDB_HIP(hipMemsetAsync(a.spill_locks, 0, (size_t)a.spill_tables * 4, s));
     launch_search(a, s);
     if (!retry_on_overflow) return;
     std::vector<vdb_query_stats> st(nq);
