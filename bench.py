@@ -120,17 +120,12 @@ def main():
         out = d_out.cpu().numpy().view(vdb.SCORED_DTYPE).reshape(Q, K)
         return out, d_n.cpu().numpy().view(np.uint32), d_stats.cpu().numpy().view(vdb.STATS_DTYPE).reshape(Q)
 
+    from vectordb_amd.sharded import ShardedIndex
+    shards = ShardedIndex(vdb, index, device=dev)
+
     def merged(out_t, n_t):
         """all-gather per-shard lists and merge them on the GPU (one exchange step)."""
-        if world == 1:
-            return out_t, n_t
-        g_out = torch.empty(world * out_t.numel(), dtype=torch.uint8, device=dev)
-        g_n = torch.empty(world * Q, dtype=torch.int32, device=dev)
-        dist.all_gather_into_tensor(g_out, out_t); dist.all_gather_into_tensor(g_n, n_t)
-        m_out = torch.empty_like(out_t); m_n = torch.empty_like(n_t)
-        cur = torch.cuda.current_stream(dev).cuda_stream
-        vdb.check(vdb.fn.topk_merge_dev(g_out.data_ptr(), g_n.data_ptr(), world, Q, K, m_out.data_ptr(), m_n.data_ptr(), cur))
-        return m_out, m_n
+        return shards.merge_dev(out_t, n_t, Q, K)
 
     # ---- ground truth: exact k-NN on the GPU (strict arithmetic, (key, id) order) ----
     t0 = time.time()

@@ -1,0 +1,116 @@
+"""Base-set sharding of the search path: one shard (vectors + its own graph) per rank.
+
+The reference holds a single in-memory segment (src/segment/segment.rs:11-18) and has no
+distributed layer; this module is the scaling axis the GPU build adds.  Every rank searches the
+FULL query batch against its shard, the per-shard top-k lists are exchanged with ONE all-gather
+(`torch.distributed`, backend "nccl" = RCCL on the GPU box, "gloo" in CPU tests), and every rank
+merges them by (sort_key ascending, id ascending) — the order `HNSWIndex::search` returns
+(src/vector/hnsw.rs:541-549) with ties broken by id.
+
+The merge itself is `vdb_topk_merge_dev` (a GPU kernel).  A backend that exports a host-buffer
+`topk_merge` (only the CPU checker does) is merged through that instead, which is how the
+world_size-2 gloo tests run without a GPU.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_range(n: int, world: int, rank: int) -> tuple[int, int]:
+    """Contiguous slot range [lo, hi) of `rank`: sizes differ by at most one, lower ranks get the extra."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    q, r = divmod(n, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def shard_of(slot: int, n: int, world: int) -> int:
+    """Rank that owns `slot` under shard_range."""
+    q, r = divmod(n, world)
+    edge = r * (q + 1)
+    return slot // (q + 1) if slot < edge else r + (slot - edge) // max(q, 1)
+
+
+class ShardedIndex:
+    """A rank's shard plus the exchange step.
+
+    `api` is the bound library namespace (`vectordb_amd.api()`), `index` the rank-local
+    `api.HNSWIndex`.  `world == 1` (or no process group) makes every call a plain local search.
+    """
+
+    def __init__(self, api, index, group=None, device=None):
+        self.api, self.index, self.group, self.device = api, index, group, device
+        self.rank, self.world = 0, 1
+        if group is not None or _dist_ready():
+            import torch.distributed as dist
+            self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    # ---- host-buffer path -------------------------------------------------------------------------
+    def search_batch(self, queries, top_k, ef_search=0):
+        out, cnt = self.index.search_batch(queries, top_k, ef_search=ef_search)
+        return self.merge(out, cnt)
+
+    def exact_knn_batch(self, queries, top_k):
+        out, cnt = self.index.exact_knn_batch(queries, top_k)
+        return self.merge(out, cnt)
+
+    def merge(self, out, cnt):
+        """All-gather the per-shard (nq x k) lists and merge them; returns (nq x k, counts) on every rank."""
+        if self.world == 1:
+            return out, cnt
+        import torch
+        import torch.distributed as dist
+        nq, k = out.shape
+        on_gpu = dist.get_backend(self.group) == "nccl"
+        dev = self._torch_device() if on_gpu else torch.device("cpu")
+        t_out = torch.from_numpy(np.ascontiguousarray(out).view(np.uint8).reshape(-1)).to(dev)
+        t_cnt = torch.from_numpy(np.ascontiguousarray(cnt).view(np.int32)).to(dev)
+        g_out = torch.empty(self.world * t_out.numel(), dtype=torch.uint8, device=dev)
+        g_cnt = torch.empty(self.world * nq, dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(g_out, t_out, group=self.group)
+        dist.all_gather_into_tensor(g_cnt, t_cnt, group=self.group)
+        fn = self.api.fn
+        if hasattr(fn, "topk_merge"):                       # host-buffer merge: the CPU checker only
+            lists = g_out.cpu().numpy().view(self.api.SCORED_DTYPE)
+            counts = g_cnt.cpu().numpy().view(np.uint32)
+            m_out = np.zeros((nq, k), dtype=self.api.SCORED_DTYPE); m_cnt = np.zeros(nq, dtype=np.uint32)
+            self.api.check(fn.topk_merge(lists.ctypes.data, counts.ctypes.data, self.world, nq, k, m_out.ctypes.data, m_cnt.ctypes.data))
+            return m_out, m_cnt
+        gdev = self._torch_device()
+        m_out, m_cnt = self.merge_dev(g_out.to(gdev), g_cnt.to(gdev), nq, k, gathered=True)
+        torch.cuda.synchronize(gdev)
+        return (m_out.cpu().numpy().view(self.api.SCORED_DTYPE).reshape(nq, k), m_cnt.cpu().numpy().view(np.uint32))
+
+    # ---- device-resident path ---------------------------------------------------------------------
+    def merge_dev(self, d_out, d_cnt, nq, k, gathered=False):
+        """d_out: uint8 tensor of nq*k*16 B (or world x that when `gathered`), d_cnt: int32 tensor of nq
+        (world x nq).  Runs on torch's current stream of the tensors' device; returns device tensors."""
+        import torch
+        if self.world == 1 and not gathered:
+            return d_out, d_cnt
+        if not gathered:
+            import torch.distributed as dist
+            g_out = torch.empty(self.world * d_out.numel(), dtype=torch.uint8, device=d_out.device)
+            g_cnt = torch.empty(self.world * nq, dtype=torch.int32, device=d_out.device)
+            dist.all_gather_into_tensor(g_out, d_out, group=self.group)
+            dist.all_gather_into_tensor(g_cnt, d_cnt, group=self.group)
+            d_out, d_cnt = g_out, g_cnt
+        m_out = torch.empty(nq * k * 16, dtype=torch.uint8, device=d_out.device)
+        m_cnt = torch.empty(nq, dtype=torch.int32, device=d_out.device)
+        cur = torch.cuda.current_stream(d_out.device).cuda_stream
+        self.api.check(self.api.fn.topk_merge_dev(d_out.data_ptr(), d_cnt.data_ptr(), self.world, nq, k,
+                                                  m_out.data_ptr(), m_cnt.data_ptr(), cur))
+        return m_out, m_cnt
+
+    def _torch_device(self):
+        import torch
+        return torch.device("cuda", torch.cuda.current_device()) if self.device is None else torch.device(self.device)
+
+
+def _dist_ready():
+    try:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized()
+    except Exception:
+        return False
