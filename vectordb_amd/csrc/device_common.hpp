@@ -19,6 +19,10 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
 __device__ __forceinline__ int popc64(uint64_t m) { return __popcll(m); }
 __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (lane == 0) ? 0ull : (~0ull >> (64 - lane)); }
+// Number of set bits of `m` below this lane (v_mbcnt pair).
+__device__ __forceinline__ uint32_t rank_below(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
 __device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 __device__ __forceinline__ uint32_t readlane_u(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 // Every search block is a single wavefront and the LDS executes one wavefront's DS instructions in

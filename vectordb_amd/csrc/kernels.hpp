@@ -63,6 +63,13 @@ struct SearchArgs {
 // flags reported per query in vdb_query_stats.flags
 enum : uint32_t { QF_HASH_OVERFLOW = 1u, QF_FILTER_ERROR = 2u, QF_CAND_OVERFLOW = 4u };
 
+// 64-entry chunks of the register-resident layer-0 result list (FAST arithmetic, unfiltered search
+// and graph construction, ef up to 256); 0 = the list lives in LDS.
+inline uint32_t reg_list_chunks(const SearchArgs& a) {
+    if (a.arith != VDB_ARITH_FAST || (a.mode != MODE_SEARCH && a.mode != MODE_BUILD) || a.ef == 0 || a.ef > 256) return 0;
+    return (a.ef + 63u) / 64u;
+}
+
 void launch_search(const SearchArgs& a, hipStream_t s);
 size_t search_lds_bytes(const SearchArgs& a);
 

@@ -15,12 +15,16 @@ namespace {
 #define VDB_T_MARK(i) do { } while (0)
 #endif
 
-template <int MODE, int G, int CH, int PASSES, bool STRICT, int METRIC>
+template <int MODE, int G, int CH, int PASSES, bool STRICT, int METRIC, int NC>
 struct Searcher {
 #ifdef VDB_TIMING
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
 #endif
     static constexpr int GG = G > 0 ? G : 8, CC = CH > 0 ? CH : 1, PP = PASSES > 0 ? PASSES : 1;
+    static constexpr int RPP = WAVE / GG;          // rows one wave instruction covers
+    static constexpr int BATCH = RPP * PP;         // rows scored together by score_batch
+    static constexpr int NCC = NC > 0 ? NC : 1;
+    uint2* perm = nullptr;                         // NC * 64 {key, slot} pairs: staging area of the register-resident list
     const SearchArgs& a;
     const GraphView& gv;
     float* qlds; uint32_t* cand; float* craw;
@@ -255,6 +259,205 @@ struct Searcher {
         }
     }
 
+    // Scores cand[base .. min(base + BATCH, m)): lane r*G + g receives, for every row group p, the raw
+    // score of candidate base + p*RPP + r in raw[p] and its slot in cs[p] (all G lanes of the group
+    // hold the same pair).  Lanes beyond the last candidate repeat it, so no lane is masked off.
+    __device__ __forceinline__ void score_batch(int base, int m, float (&raw)[PP], uint32_t (&cs)[PP]) {
+        const int lane = lane_id(), g = lane % GG, r = lane / GG;
+        const uint32_t nchunks = gv.stride >> 2;
+        const bool full = nchunks == (uint32_t)(GG * CC);
+        float4 x[PP][CC];
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+            const int ci = base + p * RPP + r;
+            cs[p] = cand[ci < m ? ci : m - 1];
+        }
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+            if (p == 0 || base + p * RPP < m) {
+                const float4* row = reinterpret_cast<const float4*>(gv.vecs + (size_t)cs[p] * gv.stride);
+#pragma unroll
+                for (int j = 0; j < CC; ++j) {
+                    const uint32_t c = g + GG * j;
+                    x[p][j] = row[(full || c < nchunks) ? c : 0u];
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+            raw[p] = 0.f;
+            if (p == 0 || base + p * RPP < m) {
+                float acc = 0.f, accb = 0.f;
+#pragma unroll
+                for (int j = 0; j < CC; ++j) {
+                    const float4 q = qr.q[j];
+                    float4 v = x[p][j];
+                    if (!full && (uint32_t)(g + GG * j) >= nchunks) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (metric() == VDB_EUCLIDEAN) {
+                        float d0 = q.x - v.x, d1 = q.y - v.y, d2 = q.z - v.z, d3 = q.w - v.w;
+                        acc = __builtin_fmaf(d0, d0, acc); acc = __builtin_fmaf(d1, d1, acc);
+                        acc = __builtin_fmaf(d2, d2, acc); acc = __builtin_fmaf(d3, d3, acc);
+                    } else {
+                        acc = __builtin_fmaf(q.x, v.x, acc); acc = __builtin_fmaf(q.y, v.y, acc);
+                        acc = __builtin_fmaf(q.z, v.z, acc); acc = __builtin_fmaf(q.w, v.w, acc);
+                        if (metric() == VDB_COSINE) {
+                            accb = __builtin_fmaf(v.x, v.x, accb); accb = __builtin_fmaf(v.y, v.y, accb);
+                            accb = __builtin_fmaf(v.z, v.z, accb); accb = __builtin_fmaf(v.w, v.w, accb);
+                        }
+                    }
+                }
+                acc = group_sum<GG>(acc);
+                if (metric() == VDB_EUCLIDEAN) raw[p] = __builtin_sqrtf(acc);
+                else if (metric() == VDB_DOT) raw[p] = acc;
+                else {
+                    accb = group_sum<GG>(accb);
+                    raw[p] = 1.0f - acc / (qr.qnorm * __builtin_sqrtf(accb) + 1e-10f);
+                }
+            }
+        }
+    }
+
+    // hnsw.rs:420-511 on layer 0 with the result list held in registers: entry c*64 + lane of the
+    // ascending list lives in (rk[c], rv[c]) of that lane, empty positions hold (+inf, expanded).
+    // Selection of the next node is a ballot over the expanded flags; candidates are merged by
+    // rank (same outcome as one insert per candidate in list order, hnsw.rs:486-499) and the
+    // permutation goes through `perm` in LDS once per merge.  On return the list is in R (LDS).
+    __device__ __forceinline__ void beam_reg(uint32_t entry, uint32_t ef) {
+        const int lane = lane_id(), g = lane % GG, r = lane / GG;
+        const float INF = __int_as_float(0x7f800000);
+        float rk[NCC]; uint32_t rv[NCC];
+#pragma unroll
+        for (int c = 0; c < NCC; ++c) { rk[c] = INF; rv[c] = FLAG_EXPANDED; }
+        const uint32_t cap = ef;
+        uint32_t n = 0;
+        float worst = INF;
+        float raw[PP]; uint32_t cs[PP];
+        reset_visited();
+        uint32_t start = entry;
+        if (is_deleted(entry) && a.fallback_live != NONE32) start = a.fallback_live;      // hnsw.rs:440-444
+        if (lane == 0) { cand[0] = start; vis.insert(start); }
+        note_visited(1);
+        wave_sync();
+        score_batch(0, 1, raw, cs);
+        rows_scored += 1;
+        {
+            const float k0 = key_of(readlane_f(raw[0], 0));
+            if (lane == 0) { rk[0] = k0; rv[0] = start; }
+            n = 1;
+            if (cap == 1) worst = k0;
+        }
+        uint32_t pf_slot = NONE32, pf_word = 0;
+#ifdef VDB_TIMING
+        tlast = clock64();
+#endif
+        for (;;) {
+            // best and second best unexpanded entries
+            uint32_t cur = NONE32, cur2 = NONE32;
+#pragma unroll
+            for (int c = 0; c < NCC; ++c) {
+                if (cur2 == NONE32 && (uint32_t)(c * WAVE) < n) {
+                    uint64_t um = ballot(!(rv[c] & FLAG_EXPANDED));
+                    if (um) {
+                        if (cur == NONE32) {
+                            const int l = __ffsll((unsigned long long)um) - 1;
+                            cur = readlane_u(rv[c], l);
+                            if (lane == l) rv[c] |= FLAG_EXPANDED;
+                            um &= um - 1;
+                        }
+                        if (um) cur2 = readlane_u(rv[c], __ffsll((unsigned long long)um) - 1);
+                    }
+                }
+            }
+            if (cur == NONE32) break;
+            VDB_T_MARK(0);
+            const uint32_t w = (cur == pf_slot) ? pf_word : load_adj_word(gv, cur);
+            pf_slot = NONE32;
+            const Adj A = open_adj0(gv, w);
+            VDB_T_MARK(1);
+            if (A.deg == 0) continue;
+            ++expanded; adj_entries += A.deg;
+            const uint32_t nchunks = A.chunks();
+            for (uint32_t ch = 0; ch < nchunks; ++ch) {
+                uint32_t nb;
+                const bool in = A.get(ch, nb);
+                bool fresh = in && !is_deleted(nb);                           // hnsw.rs:475
+                if (fresh) fresh = vis.insert(nb);
+                const uint64_t mk = ballot(fresh);
+                const int m = popc64(mk);
+                VDB_T_MARK(2);
+                if (m == 0) continue;
+                note_visited(m);
+                if (fresh) cand[rank_below(mk)] = nb;
+                wave_sync();
+                rows_scored += m;
+                for (int base = 0; base < m; base += BATCH) {
+                    // the runner-up's adjacency block is requested together with the row gather
+                    if (cur2 != NONE32 && pf_slot == NONE32) { pf_slot = cur2; pf_word = load_adj_word(gv, cur2); }
+                    score_batch(base, m, raw, cs);
+                    VDB_T_MARK(3);
+                    // lane r*G + g with g < PP owns candidate j = g*RPP + r of this batch
+                    float kown = raw[0]; uint32_t sown = cs[0];
+#pragma unroll
+                    for (int p = 1; p < PP; ++p) if (g == p) { kown = raw[p]; sown = cs[p]; }
+                    kown = key_of(kown);
+                    const int jown = g * RPP + r;
+                    bool pass = g < PP && base + jown < m;
+                    pass = pass && (n < cap || kown < worst);                 // hnsw.rs:486
+                    const uint64_t pm = ballot(pass);
+                    if (pm) {
+                        const uint32_t mp = popc64(pm);
+                        uint32_t sh[NCC], mypos = 0;
+#pragma unroll
+                        for (int c = 0; c < NCC; ++c) sh[c] = 0;
+                        uint64_t it = pm;
+                        while (it) {
+                            const int l = __ffsll((unsigned long long)it) - 1; it &= it - 1;
+                            const float k = readlane_f(kown, l);
+                            const int jj = (l % GG) * RPP + l / GG;
+                            uint32_t pos = 0;
+#pragma unroll
+                            for (int c = 0; c < NCC; ++c) {
+                                const bool gt = rk[c] > k;                    // existing entries that move back by one
+                                pos += WAVE - popc64(ballot(gt));
+                                sh[c] += gt ? 1u : 0u;
+                            }
+                            pos += popc64(ballot(pass && (kown < k || (kown == k && jown < jj))));
+                            if (lane == l) mypos = pos;
+                        }
+#pragma unroll
+                        for (int c = 0; c < NCC; ++c) {
+                            const uint32_t np = c * WAVE + lane + sh[c];
+                            if (np < NCC * WAVE) perm[np] = make_uint2(__float_as_uint(rk[c]), rv[c]);
+                        }
+                        if (pass && mypos < NCC * WAVE) perm[mypos] = make_uint2(__float_as_uint(kown), sown);
+                        n = (n + mp < cap) ? n + mp : cap;
+                        wave_sync();
+#pragma unroll
+                        for (int c = 0; c < NCC; ++c) {
+                            const uint2 e = perm[c * WAVE + lane];
+                            rk[c] = __uint_as_float(e.x); rv[c] = e.y;
+                        }
+                        if ((uint32_t)((NCC - 1) * WAVE + lane) >= cap) { rk[NCC - 1] = INF; rv[NCC - 1] = FLAG_EXPANDED; }
+                        wave_sync();
+                        worst = (n >= cap) ? readlane_f(rk[NCC - 1], (int)((cap - 1) & 63u)) : INF;
+                    }
+                    VDB_T_MARK(4);
+                }
+                if (!visited_room()) return;
+                VDB_T_MARK(5);
+            }
+            if (cur2 != NONE32 && pf_slot == NONE32) { pf_slot = cur2; pf_word = load_adj_word(gv, cur2); }   // nothing new was scored
+        }
+        // hand the list over in LDS
+#pragma unroll
+        for (int c = 0; c < NCC; ++c) {
+            const uint32_t i = c * WAVE + lane;
+            if (i < n) { R.key[i] = rk[c]; R.val[i] = rv[c]; }
+        }
+        R.n = n; R.cap = cap;
+        wave_sync();
+    }
+
     // hnsw.rs:585-689 as written.  C is an unsorted array in global scratch; R (inverted order in
     // the reference) keeps the ef LARGEST keys among entry + passing nodes and `bound` is its
     // smallest key; output is descending by key.
@@ -353,19 +556,33 @@ struct Searcher {
         // ---- carve LDS (every offset a multiple of 16 bytes) ----
         const uint32_t ef_cap = (a.ef + 63u) & ~63u;
         size_t off = 0;
-        R.key = reinterpret_cast<float*>(smem + off); off += ef_cap * 4;
-        R.val = reinterpret_cast<uint32_t*>(smem + off); off += ef_cap * 4;
-        R.key2 = reinterpret_cast<float*>(smem + off); off += ef_cap * 4;
-        R.val2 = reinterpret_cast<uint32_t*>(smem + off); off += ef_cap * 4;
-        if (MODE == MODE_MASKED) {
-            P.key = reinterpret_cast<float*>(smem + off); off += ef_cap * 4;
-            P.val = reinterpret_cast<uint32_t*>(smem + off); off += ef_cap * 4;
-            P.key2 = reinterpret_cast<float*>(smem + off); off += ef_cap * 4;
-            P.val2 = reinterpret_cast<uint32_t*>(smem + off); off += ef_cap * 4;
+        if (NC > 0 && MODE == MODE_SEARCH) {
+            // register-resident list: LDS only stages permutations, the query (until it is in
+            // registers) and the final list, all in one area
+            const size_t area = (size_t)NCC * WAVE * 8 > (size_t)gv.stride * 4 ? (size_t)NCC * WAVE * 8 : (size_t)gv.stride * 4;
+            perm = reinterpret_cast<uint2*>(smem);
+            qlds = reinterpret_cast<float*>(smem);
+            R.key = reinterpret_cast<float*>(smem); R.val = reinterpret_cast<uint32_t*>(smem) + NCC * WAVE;
+            R.key2 = nullptr; R.val2 = nullptr;
+            off = (area + 15) & ~(size_t)15;
+            cand = reinterpret_cast<uint32_t*>(smem + off); off += WAVE * 4;
+            craw = reinterpret_cast<float*>(smem + off); off += WAVE * 4;
+        } else {
+            R.key = reinterpret_cast<float*>(smem + off); off += ef_cap * 4;
+            R.val = reinterpret_cast<uint32_t*>(smem + off); off += ef_cap * 4;
+            R.key2 = reinterpret_cast<float*>(smem + off); off += ef_cap * 4;
+            R.val2 = reinterpret_cast<uint32_t*>(smem + off); off += ef_cap * 4;
+            if (MODE == MODE_MASKED) {
+                P.key = reinterpret_cast<float*>(smem + off); off += ef_cap * 4;
+                P.val = reinterpret_cast<uint32_t*>(smem + off); off += ef_cap * 4;
+                P.key2 = reinterpret_cast<float*>(smem + off); off += ef_cap * 4;
+                P.val2 = reinterpret_cast<uint32_t*>(smem + off); off += ef_cap * 4;
+            }
+            if (NC > 0) { perm = reinterpret_cast<uint2*>(smem + off); off += (size_t)NCC * WAVE * 8; }
+            cand = reinterpret_cast<uint32_t*>(smem + off); off += WAVE * 4;
+            craw = reinterpret_cast<float*>(smem + off); off += WAVE * 4;
+            qlds = reinterpret_cast<float*>(smem + off); off += (size_t)gv.stride * 4;
         }
-        cand = reinterpret_cast<uint32_t*>(smem + off); off += WAVE * 4;
-        craw = reinterpret_cast<float*>(smem + off); off += WAVE * 4;
-        qlds = reinterpret_cast<float*>(smem + off); off += (size_t)gv.stride * 4;
         vis.mask = (1u << (a.hash_log2 - 2)) - 1; vis.shift = 32 - (a.hash_log2 - 2);
         vis.limit = (1u << a.hash_log2) - (1u << a.hash_log2) / 4 - WAVE;
         vis.tab = reinterpret_cast<uint32_t*>(smem + off);
@@ -389,7 +606,7 @@ struct Searcher {
             if (norm != 0.0f) for (uint32_t i = lane; i < gv.dim; i += WAVE) qlds[i] = qlds[i] / norm;
             wave_sync();
         }
-        if (!STRICT) qr.load(qlds, gv.stride, metric());
+        if (!STRICT) { qr.load(qlds, gv.stride, metric()); wave_sync(); }
 
         if (MODE == MODE_LITERAL) {
             uint32_t cur = a.q_entry ? a.q_entry[q] : a.entry;
@@ -401,7 +618,8 @@ struct Searcher {
             uint32_t cur = a.entry;
             for (uint32_t l = a.max_level; l > lvl; --l) cur = greedy(cur, l);          // hnsw.rs:169-173
             for (int l = (int)lvl; l >= 0; --l) {                                       // hnsw.rs:175-199
-                if (l == 0) beam<false, true>(cur, 0, a.ef); else beam<false, false>(cur, (uint32_t)l, a.ef);
+                if (l == 0) { if (NC > 0) beam_reg(cur, a.ef); else beam<false, true>(cur, 0, a.ef); }
+                else beam<false, false>(cur, (uint32_t)l, a.ef);
                 if (flags & QF_HASH_OVERFLOW) break;
                 const uint32_t cnt = R.n < a.m ? R.n : a.m;
                 const size_t row = (size_t)a.nb_off[q] + (uint32_t)l;
@@ -415,7 +633,10 @@ struct Searcher {
             uint32_t cur = a.entry;
             for (uint32_t l = a.max_level; l >= 1; --l) cur = greedy(cur, l);           // hnsw.rs:538-541
             if (MODE == MODE_MASKED) { beam<true, true>(cur, 0, a.ef); if (!(flags & QF_HASH_OVERFLOW)) emit(q, P, false); }
-            else { beam<false, true>(cur, 0, a.ef); if (!(flags & QF_HASH_OVERFLOW)) emit(q, R, false); }
+            else {
+                if (NC > 0) beam_reg(cur, a.ef); else beam<false, true>(cur, 0, a.ef);
+                if (!(flags & QF_HASH_OVERFLOW)) emit(q, R, false);
+            }
         }
         if (spill_idx != NONE32) {                                          // hand the spill table back
             __threadfence();
@@ -434,26 +655,41 @@ struct Searcher {
     }
 };
 
-template <int MODE, int G, int CH, int PASSES, bool STRICT, int METRIC>
+template <int MODE, int G, int CH, int PASSES, bool STRICT, int METRIC, int NC>
 __global__ void __launch_bounds__(64) search_kernel(SearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    Searcher<MODE, G, CH, PASSES, STRICT, METRIC> s(a);
+    Searcher<MODE, G, CH, PASSES, STRICT, METRIC, NC> s(a);
     s.run(blockIdx.x, smem);
 }
 
-// FAST shapes: rows up to 128 floats use 8 lanes x 4 chunks (8 rows per wave instruction, 32 rows
-// in flight), up to 1024 floats the whole wave per row x 4 chunks, up to 2048 floats x 8 chunks.
+// FAST shapes: rows up to 128 floats use 8 lanes x 4 chunks (8 rows per wave instruction), up to
+// 1024 floats the whole wave per row x 4 chunks, up to 2048 floats x 8 chunks.  NC > 0 selects the
+// register-resident layer-0 list of NC x 64 entries (reg_list_chunks()).
+template <int MODE, int METRIC, int NC>
+void launch_search_shape(const SearchArgs& a, size_t lds, hipStream_t st) {
+    const uint32_t chunks = a.g.stride / 4;
+    constexpr int P8 = NC > 0 ? 2 : 4;             // row groups in flight per lane for short rows
+    if (chunks <= 32) hipLaunchKernelGGL((search_kernel<MODE, 8, 4, P8, false, METRIC, NC>), dim3(a.nq), dim3(64), lds, st, a);
+    else if (chunks <= 256) hipLaunchKernelGGL((search_kernel<MODE, 64, 4, 8, false, METRIC, NC>), dim3(a.nq), dim3(64), lds, st, a);
+    else if (chunks <= 512) hipLaunchKernelGGL((search_kernel<MODE, 64, 8, 4, false, METRIC, NC>), dim3(a.nq), dim3(64), lds, st, a);
+    else throw Failure(err_arg("dimension above 2048 is not supported"));
+}
 template <int MODE, int METRIC>
 void launch_search_fast(const SearchArgs& a, size_t lds, hipStream_t st) {
-    const uint32_t chunks = a.g.stride / 4;
-    if (chunks <= 32) hipLaunchKernelGGL((search_kernel<MODE, 8, 4, 4, false, METRIC>), dim3(a.nq), dim3(64), lds, st, a);
-    else if (chunks <= 256) hipLaunchKernelGGL((search_kernel<MODE, 64, 4, 8, false, METRIC>), dim3(a.nq), dim3(64), lds, st, a);
-    else if (chunks <= 512) hipLaunchKernelGGL((search_kernel<MODE, 64, 8, 4, false, METRIC>), dim3(a.nq), dim3(64), lds, st, a);
-    else throw Failure(err_arg("dimension above 2048 is not supported"));
+    if (MODE == MODE_SEARCH || MODE == MODE_BUILD) {
+        switch (reg_list_chunks(a)) {
+            case 1: launch_search_shape<MODE, METRIC, 1>(a, lds, st); return;
+            case 2: launch_search_shape<MODE, METRIC, 2>(a, lds, st); return;
+            case 3: launch_search_shape<MODE, METRIC, 3>(a, lds, st); return;
+            case 4: launch_search_shape<MODE, METRIC, 4>(a, lds, st); return;
+            default: break;
+        }
+    }
+    launch_search_shape<MODE, METRIC, 0>(a, lds, st);
 }
 template <int MODE>
 void launch_search_strict(const SearchArgs& a, size_t lds, hipStream_t st) {
-    hipLaunchKernelGGL((search_kernel<MODE, 0, 0, 0, true, -1>), dim3(a.nq), dim3(64), lds, st, a);
+    hipLaunchKernelGGL((search_kernel<MODE, 0, 0, 0, true, -1, 0>), dim3(a.nq), dim3(64), lds, st, a);
 }
 
 }  // namespace
