@@ -96,7 +96,11 @@ typedef struct {
     int32_t  device;      /* HIP device ordinal */
     int32_t  arith;       /* vdb_arith */
     int32_t  filter_mode; /* vdb_filter_mode */
-    int32_t  reserved;
+    int32_t  beam_width;  /* FAST arithmetic only: nodes expanded per step of the layer-0 beam, 1..4;
+                           * 0 = library default (4).  1 expands strictly best-first like
+                           * hnsw.rs:448-505; wider steps expand the best few unexpanded entries
+                           * together (same ef, same termination; recall equal or higher, ids may
+                           * differ where the order of expansion matters).  STRICT always uses 1. */
 } vdb_options;
 
 /* Per-query work counters written by the search kernels (extension; the reference has none). */

@@ -103,7 +103,7 @@ STATS_DTYPE = np.dtype([("rows_scored", "<u4"), ("expanded", "<u4"), ("adj_entri
 
 class OptionsC(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("device", C.c_int32), ("arith", C.c_int32),
-                ("filter_mode", C.c_int32), ("reserved", C.c_int32)]
+                ("filter_mode", C.c_int32), ("beam_width", C.c_int32)]
 
 
 class LayerCsrC(C.Structure):
@@ -373,11 +373,11 @@ def bind(cdll, prefix="vdb_", required=None):
         """HNSWIndex (hnsw.rs:59-765)."""
 
         def __init__(self, metric, m, ef, max_level_cap, dim, *, seed=0, device=0, arith=Arith.Fast,
-                     filter_mode=FilterMode.Literal, _handle=None, _owned=True, _keep=None):
+                     filter_mode=FilterMode.Literal, beam_width=0, _handle=None, _owned=True, _keep=None):
             if _handle is not None:
                 self._h, self._owned, self._keep = _handle, _owned, _keep
                 return
-            opts = OptionsC(seed, device, int(arith), int(filter_mode), 0)
+            opts = OptionsC(seed, device, int(arith), int(filter_mode), int(beam_width))
             h = C.c_void_p()
             check(fn.index_new(int(metric), m, ef, max_level_cap, dim, C.cast(C.byref(opts), _VP), C.byref(h)))
             self._h, self._owned, self._keep = h.value, True, None

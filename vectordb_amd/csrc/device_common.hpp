@@ -308,48 +308,128 @@ struct SortedList {
 };
 
 // Visited set (the per-call HashSet of hnsw.rs:435): exact, open addressing over slot ids with
-// bucketed probing.  The primary table lives in LDS; once it holds `limit` ids it is frozen and
-// further ids go to a spill table in HBM taken from a per-launch pool, so lookups stay exact at
-// any search length.
+// bucketed probing (16-byte buckets of four ids, filled front to back, never emptied).  The primary
+// table lives in LDS; once it holds `limit` ids it is frozen and further ids go to a spill table in
+// HBM taken from a per-launch pool, so lookups stay exact at any search length.
 struct Visited {
-    uint32_t* tab; uint32_t mask, shift, count, limit;         // mask/shift address 16-byte buckets of four ids
+    uint32_t* tab; uint32_t mask, shift, count, limit;         // mask/shift address the buckets
     uint32_t* spill; uint32_t smask, sshift, scount, slimit;   // spill == nullptr until needed
-    // One 16-byte read shows a whole bucket: a hit ends the probe, a free slot takes one CAS.
-    // FROZEN: look only (the primary table after it filled up).
-    // HBM: the bucket is read with device-scope atomic loads — the table is written by atomics that
-    // bypass this CU's vector L1, so a plain load could keep returning a stale line and the retry
-    // below would never end.
+    static constexpr uint32_t HASH_MUL = 2654435761u;
+
+    // One bucket against id s: 0 = s is present, 1..4 = (first free slot + 1), 5 = full without s.
+    static __device__ __forceinline__ uint32_t classify(const uint4 v, uint32_t s) {
+        const uint32_t d = min(min(v.x ^ s, v.y ^ s), min(v.z ^ s, v.w ^ s));
+        const uint32_t fr = v.x == HASH_EMPTY ? 1u : v.y == HASH_EMPTY ? 2u : v.z == HASH_EMPTY ? 3u : v.w == HASH_EMPTY ? 4u : 5u;
+        return d == 0 ? 0u : fr;
+    }
+    // HBM buckets are read with device-scope atomic loads: the table is written by atomics that
+    // bypass this CU's vector L1, so a plain load could keep returning a stale line.
+    static __device__ __forceinline__ uint4 load_bucket_hbm(uint32_t* t, uint32_t b) {
+        unsigned long long* p = reinterpret_cast<unsigned long long*>(t + 4 * b);
+        const unsigned long long lo = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long hi = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+    }
+    // Generic probe: 0 = already present, 1 = inserted, 2 = absent (FROZEN: look only).
     template <bool FROZEN, bool HBM> static __device__ __forceinline__ int probe(uint32_t* t, uint32_t bmask, uint32_t b, uint32_t s) {
         for (;;) {
-            uint4 v;
-            if (HBM) {
-                v.x = __hip_atomic_load(t + 4 * b + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                v.y = __hip_atomic_load(t + 4 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                v.z = __hip_atomic_load(t + 4 * b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                v.w = __hip_atomic_load(t + 4 * b + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else v = *reinterpret_cast<const uint4*>(t + 4 * b);
-            if (v.x == s || v.y == s || v.z == s || v.w == s) return 0;            // already visited
-            const int e = v.x == HASH_EMPTY ? 0 : v.y == HASH_EMPTY ? 1 : v.z == HASH_EMPTY ? 2 : v.w == HASH_EMPTY ? 3 : -1;
-            if (e < 0) { b = (b + 1) & bmask; continue; }                          // bucket full: next bucket
-            if (FROZEN) return 2;                                                 // not here
-            const uint32_t old = atomicCAS(&t[4 * b + e], HASH_EMPTY, s);
-            if (old == HASH_EMPTY) return 1;                                      // inserted
+            const uint4 v = HBM ? load_bucket_hbm(t, b) : *reinterpret_cast<const uint4*>(t + 4 * b);
+            const uint32_t c = classify(v, s);
+            if (c == 0) return 0;
+            if (c == 5) { b = (b + 1) & bmask; continue; }                         // bucket full: next bucket
+            if (FROZEN) return 2;
+            const uint32_t old = atomicCAS(&t[4 * b + c - 1], HASH_EMPTY, s);
+            if (old == HASH_EMPTY) return 1;
             if (old == s) return 0;
             // another lane took the slot: look at the same bucket again
         }
     }
     __device__ __forceinline__ bool insert(uint32_t s) {
-        const uint32_t hv = s * 2654435761u;
+        const uint32_t hv = s * HASH_MUL;
         if (!spill) return probe<false, false>(tab, mask, hv >> shift, s) == 1;
         if (probe<true, false>(tab, mask, hv >> shift, s) == 0) return false;
-        // HBM table: one CAS on the id's preferred slot of its bucket settles almost every lookup in
-        // a single round trip (slots are never emptied, so an id stored elsewhere in the probe
-        // sequence implies its preferred slot is taken and the CAS cannot report EMPTY for it).
-        const uint32_t b = hv >> sshift;
-        const uint32_t old = atomicCAS(&spill[4 * b + ((hv >> 4) & 3u)], HASH_EMPTY, s);
-        if (old == HASH_EMPTY) return true;
-        if (old == s) return false;
-        return probe<false, true>(spill, smask, b, s) == 1;
+        return probe<false, true>(spill, smask, hv >> sshift, s) == 1;
+    }
+    // E independent ids per lane (one per neighbour chunk): the first bucket read and the first
+    // CAS of all E are in flight together, so a step costs one LDS (or HBM) round trip per phase
+    // instead of one per chunk; lanes that need a second bucket or lost a slot finish in the
+    // generic probe, chunk by chunk.  Two lanes holding the same id (duplicates across chunks)
+    // aim at the same slot and exactly one of them reports `fresh`.
+    template <int E> __device__ __forceinline__ void insert_many(const uint32_t (&nb)[E], const bool (&want)[E], bool (&fresh)[E]) {
+        uint32_t hv[E], st[E], old[E];     // st: 0 settled (not fresh), 1..4 CAS slot + 1, 5 generic probe, 6 fresh, 7 look in HBM
+        uint4 v[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) { hv[e] = nb[e] * HASH_MUL; v[e] = *reinterpret_cast<const uint4*>(tab + 4 * (hv[e] >> shift)); }
+        if (!spill) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) st[e] = want[e] ? classify(v[e], nb[e]) : 0u;
+#pragma unroll
+            for (int e = 0; e < E; ++e) { old[e] = 0; if (st[e] >= 1 && st[e] <= 4) old[e] = atomicCAS(&tab[4 * (hv[e] >> shift) + st[e] - 1], HASH_EMPTY, nb[e]); }
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) { const uint32_t c = classify(v[e], nb[e]); st[e] = !want[e] ? 0u : c == 0 ? 0u : c == 5 ? 5u : 7u; }
+#pragma unroll
+            for (int e = 0; e < E; ++e) if (st[e] == 7) v[e] = load_bucket_hbm(spill, hv[e] >> sshift);
+#pragma unroll
+            for (int e = 0; e < E; ++e) if (st[e] == 7) st[e] = classify(v[e], nb[e]);
+#pragma unroll
+            for (int e = 0; e < E; ++e) { old[e] = 0; if (st[e] >= 1 && st[e] <= 4) old[e] = atomicCAS(&spill[4 * (hv[e] >> sshift) + st[e] - 1], HASH_EMPTY, nb[e]); }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (st[e] >= 1 && st[e] <= 4) st[e] = old[e] == HASH_EMPTY ? 6u : old[e] == nb[e] ? 0u : 5u;
+            fresh[e] = st[e] == 6;
+            if (__ballot(st[e] == 5)) { if (st[e] == 5) fresh[e] = insert(nb[e]); }
+        }
+    }
+};
+
+// Visited set of the register-resident beam: exact, 16 bits per id.  An id below 2^(bbits + 15) is
+// mapped one-to-one (odd multiplier modulo a power of two) onto a bucket number (bbits) and a 15-bit
+// tag; a bucket is 16 bytes = eight tags (bit 15 marks a used entry), filled front to back and never
+// emptied, so one ds_read_b128 shows whether the id is present and where the first free entry is.
+// Ids whose bucket is full go to a small secondary table of whole ids (Visited layout).
+struct TagSet {
+    uint32_t* tab; uint32_t idmask;
+    uint32_t* sec; uint32_t smask, sshift;
+    static constexpr uint32_t MUL = 2654435761u, USED = 0x80008000u;
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ uint32_t pkmin(uint32_t a, uint32_t b) {
+        return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+    }
+    __device__ __forceinline__ void locate(uint32_t id, uint32_t& word0, uint32_t& tag) const {
+        const uint32_t h = (id * MUL) & idmask;
+        word0 = (h >> 15) << 2; tag = (h & 0x7FFFu) | 0x8000u;
+    }
+    static __device__ __forceinline__ bool present(const uint4 v, uint32_t tag) {
+        const uint32_t t2 = tag | (tag << 16);
+        uint32_t m = pkmin(pkmin(v.x ^ t2, v.y ^ t2), pkmin(v.z ^ t2, v.w ^ t2));
+        m = pkmin(m, __builtin_amdgcn_alignbit(m, m, 16));
+        return (m & 0xFFFFu) == 0;
+    }
+    static __device__ __forceinline__ uint32_t used(const uint4 v) {
+        return __popc(v.x & USED) + __popc(v.y & USED) + __popc(v.z & USED) + __popc(v.w & USED);
+    }
+    // CAS operands that put `tag` into entry u (< 8) of bucket v
+    static __device__ __forceinline__ void slot_of(const uint4 v, uint32_t u, uint32_t tag, uint32_t& widx, uint32_t& expect, uint32_t& desired) {
+        widx = u >> 1;
+        expect = widx == 0 ? v.x : widx == 1 ? v.y : widx == 2 ? v.z : v.w;
+        desired = expect | (tag << ((u & 1u) * 16u));
+    }
+    // Generic insert: 0 = the id was already in the set, 1 = added to the tag table, 2 = added to the secondary table.
+    __device__ __forceinline__ int insert(uint32_t id) const {
+        uint32_t w0, tag;
+        locate(id, w0, tag);
+        for (;;) {
+            const uint4 v = *reinterpret_cast<const uint4*>(tab + w0);
+            if (present(v, tag)) return 0;
+            const uint32_t u = used(v);
+            if (u == 8) return Visited::probe<false, false>(sec, smask, (id * MUL) >> sshift, id) == 1 ? 2 : 0;
+            uint32_t widx, expect, desired;
+            slot_of(v, u, tag, widx, expect, desired);
+            if (atomicCAS(&tab[w0 + widx], expect, desired) == expect) return 1;
+            // the word changed under us (another lane filled this or the neighbouring entry): look again
+        }
     }
 };
 

@@ -195,12 +195,19 @@ GraphView vdb_index::view() const {
     return g;
 }
 
+uint32_t vdb_index::beam_width() const {
+    int w = opts.beam_width;
+    if (const char* e = std::getenv("VDB_BEAM_WIDTH")) w = std::atoi(e);
+    if (w <= 0) w = 4;
+    return (uint32_t)std::min(w, 4);
+}
+
 uint32_t vdb_index::pick_hash_log2(size_t, bool& global) const {
     // 4096 ids (16 KiB of LDS) keep eight search wavefronts resident per CU; a query that visits
     // more rows than that continues in a spill table in HBM (see Visited in kernels.hip)
     global = false;
     static const int forced = [] { const char* e = getenv("VDB_HASH_LOG2"); return e ? atoi(e) : 0; }();
-    return (forced >= 8 && forced <= 14) ? (uint32_t)forced : 12;
+    return (forced >= 10 && forced <= 14) ? (uint32_t)forced : 12;
 }
 
 // Launches the search.  Queries that outgrow the LDS visited table spill into HBM tables taken from
@@ -209,6 +216,8 @@ uint32_t vdb_index::pick_hash_log2(size_t, bool& global) const {
 void vdb_index::run_search(SearchArgs a, size_t nq, hipStream_t s, bool retry_on_overflow, const float* d_q_all) {
     bool global = false;
     a.hash_log2 = pick_hash_log2(a.ef, global);
+    static const int forced_tags = [] { const char* e = getenv("VDB_TAG_LOG2"); return e ? atoi(e) : 0; }();
+    a.tag_log2 = (forced_tags >= 11 && forced_tags <= 15) ? (uint32_t)forced_tags : 13;
     // one spill table per possibly resident wavefront (256 CUs x 16), 2^15 ids each
     a.spill_log2 = 15;
     a.spill_tables = 4096;
@@ -222,6 +231,13 @@ void vdb_index::run_search(SearchArgs a, size_t nq, hipStream_t s, bool retry_on
     }
     a.spill_locks = s_spill.p; a.spill_pool = s_spill.p + a.spill_tables;
     launch_search(a, s);
+    if (reg_list_chunks(a) > 0) {
+        // The register-resident beam keeps its visited set in LDS alone and flags a query that fills
+        // it.  A follow-up launch of the LDS-list kernel with its HBM spill tables, on the same
+        // stream, takes only the flagged queries (every other block leaves at once).
+        SearchArgs c = a; c.only_flagged = 1; c.force_generic = 1;
+        launch_search(c, s);
+    }
     if (!retry_on_overflow) return;
     std::vector<vdb_query_stats> st(nq);
     VDB_HIP(hipMemcpyAsync(st.data(), a.stats, nq * sizeof(vdb_query_stats), hipMemcpyDeviceToHost, s));
@@ -276,6 +292,7 @@ void vdb_index::search_batch(const float* q, size_t nq, size_t top_k, size_t ef_
     a.max_level = (uint32_t)current_max_level;
     auto fl = first_live_slot(); a.fallback_live = fl ? *fl : NONE32;
     a.ef = (uint32_t)ef_; a.top_k = (uint32_t)top_k; a.out = s_out.p; a.out_n = s_n.p; a.stats = s_stats.p;
+    a.beam_width = beam_width();
     if (fa.bits) { a.pass_bits = fa.bits->d_pass.p; a.err_bits = fa.bits->d_err.p; }
     if (fa.mode == MODE_LITERAL) {
         a.cand_cap = 16384;
@@ -310,6 +327,12 @@ void vdb_index::search_batch_dev(const float* d_q, size_t nq, size_t top_k, size
     a.entry = slot_of.at(*entry_point); a.max_level = (uint32_t)current_max_level;
     auto fl = first_live_slot(); a.fallback_live = fl ? *fl : NONE32;
     a.ef = (uint32_t)ef_; a.top_k = (uint32_t)top_k; a.out = d_out; a.out_n = d_out_n; a.stats = d_stats;
+    if (!a.stats) {                       // the follow-up launches read the flags: one private array per stream
+        auto& buf = s_stats_by_stream[s];
+        buf.reserve(nq, s, false);
+        a.stats = buf.p;
+    }
+    a.beam_width = beam_width();
     // no host round trip on this path: an overflowing query reports QF_HASH_OVERFLOW in d_stats
     run_search(a, nq, s, false, d_q);
 }
@@ -376,6 +399,7 @@ std::vector<vdb_scored_point> vdb_index::search_from_row(uint32_t row_slot, uint
     a.entry = entry_slot; a.max_level = (uint32_t)current_max_level;
     auto fl = first_live_slot(); a.fallback_live = fl ? *fl : NONE32;
     a.ef = (uint32_t)ef_search; a.top_k = (uint32_t)ef_search; a.out = s_out.p; a.out_n = s_n.p; a.stats = s_stats.p;
+    a.beam_width = 1;
     a.q_levels = s_lvl.p; a.nb_off = s_off.p; a.m = (uint32_t)m; a.nb_out = s_nb.p; a.nb_cnt = s_nbc.p;
     run_search(a, 1, stream, true, nullptr);
     uint32_t n = 0;
@@ -454,6 +478,7 @@ vdb_index::BuildResult vdb_index::build_search(const std::vector<uint32_t>& slot
     a.entry = entry_slot; a.max_level = (uint32_t)current_max_level;
     auto fl = first_live_slot(); a.fallback_live = fl ? *fl : NONE32;
     a.ef = (uint32_t)ef; a.top_k = 0; a.out = nullptr; a.out_n = s_n.p; a.stats = s_stats.p;
+    a.beam_width = 1;
     a.q_levels = s_lvl.p; a.nb_off = s_off.p; a.m = (uint32_t)m; a.nb_out = s_nb.p; a.nb_cnt = s_nbc.p;
     run_search(a, nq, stream, true, nullptr);
     VDB_HIP(hipMemcpyAsync(br.nb.data(), s_nb.p, rows * m * 4, hipMemcpyDeviceToHost, stream));

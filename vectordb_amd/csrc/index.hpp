@@ -1,6 +1,7 @@
 // Host side of libvdbmi: the HNSW index (graph producer + device-resident search) and the segment
 // wrapper, mirroring src/vector/hnsw.rs and src/segment/segment.rs.
 #pragma once
+#include <map>
 #include <memory>
 #include <mutex>
 #include <optional>
@@ -69,6 +70,7 @@ struct vdb_index {
     mutable std::mutex mu;
     mutable vdb::DevBuf<float> s_q, s_raw; mutable vdb::DevBuf<vdb_scored_point> s_out, s_knn, s_cand;
     mutable vdb::DevBuf<uint32_t> s_n, s_slots, s_lvl, s_off, s_nb, s_nbc, s_hash, s_spill; mutable vdb::DevBuf<vdb_query_stats> s_stats;
+    mutable std::map<hipStream_t, vdb::DevBuf<vdb_query_stats>> s_stats_by_stream;
 
     vdb_index(vdb_metric metric, size_t m, size_t ef, size_t cap, size_t dim, const vdb_options& o);
     ~vdb_index();
@@ -110,6 +112,7 @@ struct vdb_index {
     BuildResult build_search(const std::vector<uint32_t>& slots, uint32_t entry_slot);
     void link_point(uint32_t slot, const BuildResult& br, size_t qi);
     uint32_t pick_hash_log2(size_t ef, bool& global) const;
+    uint32_t beam_width() const;       // nodes expanded per step of the FAST layer-0 beam (vdb_options.beam_width, VDB_BEAM_WIDTH)
     void run_search(vdb::SearchArgs a, size_t nq, hipStream_t s, bool retry_on_overflow, const float* d_q_all);
 };
 

@@ -15,8 +15,10 @@ void launch_search_literal(const SearchArgs& a, size_t lds, hipStream_t st);
 size_t search_lds_bytes(const SearchArgs& a) {
     const size_t ef_cap = (a.ef + 63u) & ~63u;
     const size_t nc = reg_list_chunks(a), hash = (size_t)4 << a.hash_log2, row = (size_t)a.g.stride * 4;
-    if (nc && a.mode == MODE_SEARCH) return ((std::max(nc * 512, row) + 15) & ~(size_t)15) + 64 * 8 + hash;
-    return ef_cap * 16 + (a.mode == MODE_MASKED ? ef_cap * 16 : 0) + nc * 512 + 64 * 8 + row + hash;
+    const size_t staging = (nc ? 256 : 64) * 8;      // cand + craw
+    const size_t tags = nc ? ((size_t)2 << a.tag_log2) + 512 * 4 : 0;   // 16-bit visited table + secondary table
+    if (nc && a.mode == MODE_SEARCH) return ((std::max(nc * 512, row) + 15) & ~(size_t)15) + staging + tags;
+    return ef_cap * 16 + (a.mode == MODE_MASKED ? ef_cap * 16 : 0) + nc * 512 + tags + staging + row + hash;
 }
 
 void launch_search(const SearchArgs& a, hipStream_t st) {

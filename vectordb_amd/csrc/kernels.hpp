@@ -39,10 +39,14 @@ struct SearchArgs {
     uint32_t entry, max_level;   // entry slot (NONE32: empty index)
     uint32_t fallback_live;      // smallest-id live slot, used when the entry is tombstoned
     uint32_t ef, top_k;
+    uint32_t beam_width;         // register-resident beam: nodes expanded per step (1..4)
+    uint32_t only_flagged;       // 1: handle only queries whose stats carry QF_HASH_OVERFLOW (follow-up launches)
+    uint32_t force_generic;      // 1: LDS-resident list with HBM spill tables even where the register beam applies
     vdb_scored_point* out;       // nq x top_k
     uint32_t* out_n;             // nq
     vdb_query_stats* stats;      // nq or nullptr
     uint32_t hash_log2;          // LDS visited table capacity = 1 << hash_log2 ids
+    uint32_t tag_log2;           // register-resident beam: 16-bit visited table of 1 << tag_log2 entries (slots below 2^(tag_log2 + 12))
     uint32_t* spill_pool;        // spill tables in HBM for queries that outgrow the LDS table
     uint32_t* spill_locks;       // one word per spill table: 0 free, 1 taken (zeroed before the launch)
     uint32_t spill_tables, spill_log2;
@@ -66,7 +70,7 @@ enum : uint32_t { QF_HASH_OVERFLOW = 1u, QF_FILTER_ERROR = 2u, QF_CAND_OVERFLOW 
 // 64-entry chunks of the register-resident layer-0 result list (FAST arithmetic, unfiltered search
 // and graph construction, ef up to 256); 0 = the list lives in LDS.
 inline uint32_t reg_list_chunks(const SearchArgs& a) {
-    if (a.arith != VDB_ARITH_FAST || (a.mode != MODE_SEARCH && a.mode != MODE_BUILD) || a.ef == 0 || a.ef > 256) return 0;
+    if (a.force_generic || ((uint64_t)a.g.n >> (a.tag_log2 + 12)) != 0 || a.arith != VDB_ARITH_FAST || (a.mode != MODE_SEARCH && a.mode != MODE_BUILD) || a.ef == 0 || a.ef > 256) return 0;
     return (a.ef + 63u) / 64u;
 }
 

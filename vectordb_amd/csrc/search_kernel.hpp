@@ -24,7 +24,10 @@ struct Searcher {
     static constexpr int RPP = WAVE / GG;          // rows one wave instruction covers
     static constexpr int BATCH = RPP * PP;         // rows scored together by score_batch
     static constexpr int NCC = NC > 0 ? NC : 1;
+    static constexpr int CAND_CAP = NC > 0 ? 256 : WAVE;   // candidate staging (cand / craw) entries
     uint2* perm = nullptr;                         // NC * 64 {key, slot} pairs: staging area of the register-resident list
+    static constexpr uint32_t SEC_IDS = 512, SEC_LIMIT = 320;   // secondary visited table of the register-resident beam
+    TagSet tags; uint32_t tag_limit = 0;
     const SearchArgs& a;
     const GraphView& gv;
     float* qlds; uint32_t* cand; float* craw;
@@ -70,7 +73,7 @@ struct Searcher {
             spill_idx = idx;
             vis.spill = a.spill_pool + ((size_t)idx << a.spill_log2);
             vis.smask = (1u << (a.spill_log2 - 2)) - 1; vis.sshift = 32 - (a.spill_log2 - 2);
-            vis.slimit = (1u << a.spill_log2) - (1u << a.spill_log2) / 4 - WAVE;
+            vis.slimit = (1u << a.spill_log2) - (1u << a.spill_log2) / 4 - (NC > 0 ? 4 * WAVE : WAVE);
             for (uint32_t i = lane_id(); i <= vis.smask; i += WAVE)
                 reinterpret_cast<uint4*>(vis.spill)[i] = make_uint4(HASH_EMPTY, HASH_EMPTY, HASH_EMPTY, HASH_EMPTY);
             vis.scount = 0;
@@ -259,200 +262,282 @@ struct Searcher {
         }
     }
 
-    // Scores cand[base .. min(base + BATCH, m)): lane r*G + g receives, for every row group p, the raw
-    // score of candidate base + p*RPP + r in raw[p] and its slot in cs[p] (all G lanes of the group
-    // hold the same pair).  Lanes beyond the last candidate repeat it, so no lane is masked off.
-    __device__ __forceinline__ void score_batch(int base, int m, float (&raw)[PP], uint32_t (&cs)[PP]) {
+    // Scores cand[0 .. m) into craw[0 .. m) (both LDS) for the register-resident beam: Euclidean
+    // scores stay squared (the beam orders by them and takes the root once, when it hands the
+    // list over), sums run on packed two-float FMAs.  Lanes beyond the last candidate repeat it,
+    // so no lane is masked off.  FULL: a row fills all G x CH chunks, the stride is a constant.
+    template <bool FULL> __device__ __forceinline__ void score_rows(int m) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
         const int lane = lane_id(), g = lane % GG, r = lane / GG;
-        const uint32_t nchunks = gv.stride >> 2;
-        const bool full = nchunks == (uint32_t)(GG * CC);
-        float4 x[PP][CC];
+        const uint32_t stride = FULL ? (uint32_t)(GG * CC * 4) : gv.stride;
+        const uint32_t nchunks = stride >> 2;
+        const float* const vecs = gv.vecs;
+        for (int base = 0; base < m; base += BATCH) {
+            float4 x[PP][CC];
+            uint32_t cs[PP];
 #pragma unroll
-        for (int p = 0; p < PP; ++p) {
-            const int ci = base + p * RPP + r;
-            cs[p] = cand[ci < m ? ci : m - 1];
-        }
-#pragma unroll
-        for (int p = 0; p < PP; ++p) {
-            if (p == 0 || base + p * RPP < m) {
-                const float4* row = reinterpret_cast<const float4*>(gv.vecs + (size_t)cs[p] * gv.stride);
-#pragma unroll
-                for (int j = 0; j < CC; ++j) {
-                    const uint32_t c = g + GG * j;
-                    x[p][j] = row[(full || c < nchunks) ? c : 0u];
-                }
+            for (int p = 0; p < PP; ++p) {
+                const int ci = base + p * RPP + r;
+                cs[p] = cand[ci < m ? ci : m - 1];
             }
-        }
 #pragma unroll
-        for (int p = 0; p < PP; ++p) {
-            raw[p] = 0.f;
-            if (p == 0 || base + p * RPP < m) {
-                float acc = 0.f, accb = 0.f;
+            for (int p = 0; p < PP; ++p) {
+                if (p == 0 || base + p * RPP < m) {
+                    const float4* row = reinterpret_cast<const float4*>(vecs + (size_t)cs[p] * stride);
 #pragma unroll
-                for (int j = 0; j < CC; ++j) {
-                    const float4 q = qr.q[j];
-                    float4 v = x[p][j];
-                    if (!full && (uint32_t)(g + GG * j) >= nchunks) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (metric() == VDB_EUCLIDEAN) {
-                        float d0 = q.x - v.x, d1 = q.y - v.y, d2 = q.z - v.z, d3 = q.w - v.w;
-                        acc = __builtin_fmaf(d0, d0, acc); acc = __builtin_fmaf(d1, d1, acc);
-                        acc = __builtin_fmaf(d2, d2, acc); acc = __builtin_fmaf(d3, d3, acc);
-                    } else {
-                        acc = __builtin_fmaf(q.x, v.x, acc); acc = __builtin_fmaf(q.y, v.y, acc);
-                        acc = __builtin_fmaf(q.z, v.z, acc); acc = __builtin_fmaf(q.w, v.w, acc);
-                        if (metric() == VDB_COSINE) {
-                            accb = __builtin_fmaf(v.x, v.x, accb); accb = __builtin_fmaf(v.y, v.y, accb);
-                            accb = __builtin_fmaf(v.z, v.z, accb); accb = __builtin_fmaf(v.w, v.w, accb);
-                        }
+                    for (int j = 0; j < CC; ++j) {
+                        const uint32_t c = g + GG * j;
+                        x[p][j] = row[(FULL || c < nchunks) ? c : 0u];
                     }
                 }
-                acc = group_sum<GG>(acc);
-                if (metric() == VDB_EUCLIDEAN) raw[p] = __builtin_sqrtf(acc);
-                else if (metric() == VDB_DOT) raw[p] = acc;
-                else {
-                    accb = group_sum<GG>(accb);
-                    raw[p] = 1.0f - acc / (qr.qnorm * __builtin_sqrtf(accb) + 1e-10f);
+            }
+#pragma unroll
+            for (int p = 0; p < PP; ++p) {
+                if (p == 0 || base + p * RPP < m) {
+                    f2 acc = {0.f, 0.f}, accb = {0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < CC; ++j) {
+                        float4 v = x[p][j];
+                        if (!FULL && (uint32_t)(g + GG * j) >= nchunks) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        const f2 q0 = {qr.q[j].x, qr.q[j].y}, q1 = {qr.q[j].z, qr.q[j].w};
+                        const f2 v0 = {v.x, v.y}, v1 = {v.z, v.w};
+                        if (metric() == VDB_EUCLIDEAN) {
+                            const f2 d0 = q0 - v0, d1 = q1 - v1;
+                            acc = __builtin_elementwise_fma(d0, d0, acc); acc = __builtin_elementwise_fma(d1, d1, acc);
+                        } else {
+                            acc = __builtin_elementwise_fma(q0, v0, acc); acc = __builtin_elementwise_fma(q1, v1, acc);
+                            if (metric() == VDB_COSINE) { accb = __builtin_elementwise_fma(v0, v0, accb); accb = __builtin_elementwise_fma(v1, v1, accb); }
+                        }
+                    }
+                    const float sum = group_sum<GG>(acc.x + acc.y);
+                    float raw = sum;
+                    if (metric() == VDB_COSINE) {
+                        const float sb = group_sum<GG>(accb.x + accb.y);
+                        raw = 1.0f - sum / (qr.qnorm * __builtin_sqrtf(sb) + 1e-10f);
+                    }
+                    const int ci = base + p * RPP + r;
+                    if (g == 0 && ci < m) craw[ci] = raw;
                 }
             }
         }
+        wave_sync();
     }
 
     // hnsw.rs:420-511 on layer 0 with the result list held in registers: entry c*64 + lane of the
     // ascending list lives in (rk[c], rv[c]) of that lane, empty positions hold (+inf, expanded).
-    // Selection of the next node is a ballot over the expanded flags; candidates are merged by
-    // rank (same outcome as one insert per candidate in list order, hnsw.rs:486-499) and the
-    // permutation goes through `perm` in LDS once per merge.  On return the list is in R (LDS).
-    __device__ __forceinline__ void beam_reg(uint32_t entry, uint32_t ef) {
-        const int lane = lane_id(), g = lane % GG, r = lane / GG;
+    // Each step takes the `width` best unexpanded entries (a ballot over the expanded flags),
+    // probes the visited table for all their inline neighbours at once, scores the unvisited
+    // ones and merges them by rank — the outcome of one insert per candidate in list order
+    // (hnsw.rs:486-499); the permutation goes through `perm` in LDS once per 64 candidates.
+    // width == 1 is the reference's strictly best-first order.  Euclidean keys are squared
+    // distances until the list is handed over in R (LDS).  The visited table is the LDS table
+    // alone: a query that fills it stops and is flagged (QF_HASH_OVERFLOW) for a launch with a
+    // larger table.
+    __device__ __forceinline__ void beam_reg(uint32_t entry, uint32_t ef, uint32_t width) {
+        constexpr int EMAX = 4;
+        const int lane = lane_id();
         const float INF = __int_as_float(0x7f800000);
+        const bool full = gv.stride == (uint32_t)(GG * CC * 4);
+        uint32_t* const par_lds = reinterpret_cast<uint32_t*>(craw);     // parents pass through the head of craw
+        const uint32_t vlimit = tag_limit;
+        const TagSet ts = tags;
+        const uint32_t* const adj0 = gv.adj0;
         float rk[NCC]; uint32_t rv[NCC];
 #pragma unroll
         for (int c = 0; c < NCC; ++c) { rk[c] = INF; rv[c] = FLAG_EXPANDED; }
         const uint32_t cap = ef;
-        uint32_t n = 0;
+        uint32_t n = 0, vcount = 0, scount = 0;
         float worst = INF;
-        float raw[PP]; uint32_t cs[PP];
-        reset_visited();
+        {   // clear the visited set
+            const uint32_t words = (ts.idmask >> 15) * 4 + 4;
+            for (uint32_t i = lane * 4; i < words; i += WAVE * 4) *reinterpret_cast<uint4*>(ts.tab + i) = make_uint4(0u, 0u, 0u, 0u);
+            for (uint32_t i = lane * 4; i < SEC_IDS; i += WAVE * 4) *reinterpret_cast<uint4*>(ts.sec + i) = make_uint4(HASH_EMPTY, HASH_EMPTY, HASH_EMPTY, HASH_EMPTY);
+            wave_sync();
+        }
         uint32_t start = entry;
         if (is_deleted(entry) && a.fallback_live != NONE32) start = a.fallback_live;      // hnsw.rs:440-444
-        if (lane == 0) { cand[0] = start; vis.insert(start); }
-        note_visited(1);
+        if (lane == 0) { cand[0] = start; ts.insert(start); }
+        vcount = 1;
         wave_sync();
-        score_batch(0, 1, raw, cs);
+        if (full) score_rows<true>(1); else score_rows<false>(1);
         rows_scored += 1;
         {
-            const float k0 = key_of(readlane_f(raw[0], 0));
+            const float k0 = key_of(craw[0]);
             if (lane == 0) { rk[0] = k0; rv[0] = start; }
             n = 1;
             if (cap == 1) worst = k0;
         }
-        uint32_t pf_slot = NONE32, pf_word = 0;
+        wave_sync();
 #ifdef VDB_TIMING
         tlast = clock64();
 #endif
         for (;;) {
-            // best and second best unexpanded entries
-            uint32_t cur = NONE32, cur2 = NONE32;
+            // ---- the `width` best unexpanded entries, in list order: rank by ballot, ids through LDS ----
+            uint32_t seen = 0;
 #pragma unroll
             for (int c = 0; c < NCC; ++c) {
-                if (cur2 == NONE32 && (uint32_t)(c * WAVE) < n) {
-                    uint64_t um = ballot(!(rv[c] & FLAG_EXPANDED));
-                    if (um) {
-                        if (cur == NONE32) {
-                            const int l = __ffsll((unsigned long long)um) - 1;
-                            cur = readlane_u(rv[c], l);
-                            if (lane == l) rv[c] |= FLAG_EXPANDED;
-                            um &= um - 1;
-                        }
-                        if (um) cur2 = readlane_u(rv[c], __ffsll((unsigned long long)um) - 1);
-                    }
+                if (seen < width && (uint32_t)(c * WAVE) < n) {
+                    const bool un = (int32_t)rv[c] >= 0;
+                    const uint64_t um = ballot(un);
+                    const uint32_t rnk = seen + rank_below(um);
+                    const bool isp = un && rnk < width;
+                    if (isp) { par_lds[rnk] = rv[c]; rv[c] |= FLAG_EXPANDED; }
+                    seen += popc64(um);
                 }
             }
-            if (cur == NONE32) break;
+            const uint32_t np = seen < width ? seen : width;
+            if (np == 0) break;
+            wave_sync();
+            const uint4 pv = *reinterpret_cast<const uint4*>(par_lds);
+            const uint32_t par[EMAX] = {pv.x, pv.y, pv.z, pv.w};
             VDB_T_MARK(0);
-            const uint32_t w = (cur == pf_slot) ? pf_word : load_adj_word(gv, cur);
-            pf_slot = NONE32;
-            const Adj A = open_adj0(gv, w);
+            uint32_t w[EMAX];
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) w[e] = adj0[(size_t)par[(uint32_t)e < np ? e : 0] * ADJ_BLOCK + lane];
+            wave_sync();                     // parents are consumed before cand/craw are written again
             VDB_T_MARK(1);
-            if (A.deg == 0) continue;
-            ++expanded; adj_entries += A.deg;
-            const uint32_t nchunks = A.chunks();
-            for (uint32_t ch = 0; ch < nchunks; ++ch) {
-                uint32_t nb;
-                const bool in = A.get(ch, nb);
-                bool fresh = in && !is_deleted(nb);                           // hnsw.rs:475
-                if (fresh) fresh = vis.insert(nb);
-                const uint64_t mk = ballot(fresh);
-                const int m = popc64(mk);
+            // ---- round 0: the inline neighbours (block words 1..62) of all parents at once; further
+            // rounds: one overflow chunk of a high-degree parent each ----
+            uint32_t hub_e = 0, hub_ch = 1, hub_left = 0;     // overflow chunks of high-degree parents still to visit
+            bool room = true;
+            for (uint32_t round = 0; ; ++round) {
+                int m = 0;
+                if (round == 0) {
+                    uint32_t nb[EMAX], w0[EMAX], tag[EMAX], widx[EMAX], expect[EMAX], desired[EMAX], old[EMAX];
+                    uint4 bk[EMAX];
+                    bool tr[EMAX], fresh[EMAX], slow[EMAX];
+#pragma unroll
+                    for (int e = 0; e < EMAX; ++e) {
+                        nb[e] = w[e];
+                        ts.locate(nb[e], w0[e], tag[e]);
+                        bk[e] = *reinterpret_cast<const uint4*>(ts.tab + w0[e]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < EMAX; ++e) {
+                        uint32_t deg = (uint32_t)e < np ? readlane_u(w[e], 0) : 0u;
+                        if (deg) { ++expanded; adj_entries += deg; }
+                        hub_left += deg > ADJ_INLINE ? (deg - ADJ_INLINE + 63u) / 64u : 0u;
+                        deg = deg < ADJ_INLINE ? deg : ADJ_INLINE;
+                        bool want = (uint32_t)(lane - 1) < deg;                           // words 1..deg hold neighbours
+                        if (gv.deleted) want = want && !bit_test(gv.deleted, nb[e]);      // hnsw.rs:475
+                        const bool absent = want && !TagSet::present(bk[e], tag[e]);
+                        const uint32_t u = TagSet::used(bk[e]);
+                        tr[e] = absent && u < 8;
+                        slow[e] = absent && u == 8;                                       // full bucket: generic insert
+                        TagSet::slot_of(bk[e], u, tag[e], widx[e], expect[e], desired[e]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < EMAX; ++e) { old[e] = 0; if (tr[e]) old[e] = atomicCAS(&ts.tab[w0[e] + widx[e]], expect[e], desired[e]); }
+                    bool any_slow = false;
+#pragma unroll
+                    for (int e = 0; e < EMAX; ++e) {
+                        fresh[e] = tr[e] && old[e] == expect[e];
+                        slow[e] = slow[e] || (tr[e] && old[e] != expect[e]);              // the word changed under us
+                        any_slow = any_slow || slow[e];
+                    }
+                    if (ballot(any_slow)) {
+#pragma unroll
+                        for (int e = 0; e < EMAX; ++e) {
+                            if (ballot(slow[e])) {
+                                int r = 0;
+                                if (slow[e]) r = ts.insert(nb[e]);
+                                if (slow[e]) fresh[e] = r != 0;
+                                scount += popc64(ballot(r == 2));
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < EMAX; ++e) {
+                        const uint64_t mk = ballot(fresh[e]);
+                        if (fresh[e]) cand[m + rank_below(mk)] = nb[e];
+                        m += popc64(mk);
+                    }
+                } else {
+                    if (hub_left == 0) break;
+                    --hub_left;
+                    Adj A;
+                    for (;;) {                                                            // next overflow chunk, in parent order
+                        uint32_t we = w[0];
+#pragma unroll
+                        for (int t = 1; t < EMAX; ++t) if (hub_e == (uint32_t)t) we = w[t];
+                        A = open_adj0(gv, we);
+                        if (hub_ch < A.chunks()) break;
+                        ++hub_e; hub_ch = 1;
+                    }
+                    uint32_t nb;
+                    const bool in = A.get(hub_ch, nb);
+                    ++hub_ch;
+                    bool fresh = in && !is_deleted(nb);
+                    int r = 0;
+                    if (fresh) r = ts.insert(nb);
+                    fresh = r != 0;
+                    scount += popc64(ballot(r == 2));
+                    const uint64_t mk = ballot(fresh);
+                    if (fresh) cand[rank_below(mk)] = nb;
+                    m = popc64(mk);
+                }
                 VDB_T_MARK(2);
                 if (m == 0) continue;
-                note_visited(m);
-                if (fresh) cand[rank_below(mk)] = nb;
+                vcount += m; rows_scored += m;
                 wave_sync();
-                rows_scored += m;
-                for (int base = 0; base < m; base += BATCH) {
-                    // the runner-up's adjacency block is requested together with the row gather
-                    if (cur2 != NONE32 && pf_slot == NONE32) { pf_slot = cur2; pf_word = load_adj_word(gv, cur2); }
-                    score_batch(base, m, raw, cs);
-                    VDB_T_MARK(3);
-                    // lane r*G + g with g < PP owns candidate j = g*RPP + r of this batch
-                    float kown = raw[0]; uint32_t sown = cs[0];
-#pragma unroll
-                    for (int p = 1; p < PP; ++p) if (g == p) { kown = raw[p]; sown = cs[p]; }
-                    kown = key_of(kown);
-                    const int jown = g * RPP + r;
-                    bool pass = g < PP && base + jown < m;
-                    pass = pass && (n < cap || kown < worst);                 // hnsw.rs:486
+                if (full) score_rows<true>(m); else score_rows<false>(m);
+                VDB_T_MARK(3);
+                // ---- merge cand[0..m) / craw[0..m), 64 candidates per round, lane j <-> candidate j ----
+                for (int base = 0; base < m; base += WAVE) {
+                    const int j = base + lane;
+                    const bool have = j < m;
+                    float kj = have ? key_of(craw[j]) : INF;
+                    const uint32_t sj = have ? cand[j] : 0u;
+                    const bool pass = have && (n < cap || kj < worst);            // hnsw.rs:486
                     const uint64_t pm = ballot(pass);
-                    if (pm) {
-                        const uint32_t mp = popc64(pm);
-                        uint32_t sh[NCC], mypos = 0;
+                    if (pm == 0) continue;
+                    if (!pass) kj = INF;
+                    const uint32_t mp = popc64(pm);
+                    uint32_t sh[NCC], mypos = 0;
 #pragma unroll
-                        for (int c = 0; c < NCC; ++c) sh[c] = 0;
-                        uint64_t it = pm;
-                        while (it) {
-                            const int l = __ffsll((unsigned long long)it) - 1; it &= it - 1;
-                            const float k = readlane_f(kown, l);
-                            const int jj = (l % GG) * RPP + l / GG;
-                            uint32_t pos = 0;
-#pragma unroll
-                            for (int c = 0; c < NCC; ++c) {
-                                const bool gt = rk[c] > k;                    // existing entries that move back by one
-                                pos += WAVE - popc64(ballot(gt));
-                                sh[c] += gt ? 1u : 0u;
-                            }
-                            pos += popc64(ballot(pass && (kown < k || (kown == k && jown < jj))));
-                            if (lane == l) mypos = pos;
-                        }
+                    for (int c = 0; c < NCC; ++c) sh[c] = 0;
+                    uint64_t it = pm;
+                    while (it) {
+                        const int l = __ffsll((unsigned long long)it) - 1; it &= it - 1;
+                        const float k = readlane_f(kj, l);
+                        uint32_t pos = 0;
 #pragma unroll
                         for (int c = 0; c < NCC; ++c) {
-                            const uint32_t np = c * WAVE + lane + sh[c];
-                            if (np < NCC * WAVE) perm[np] = make_uint2(__float_as_uint(rk[c]), rv[c]);
+                            const bool gt = rk[c] > k;                            // existing entries that move back by one
+                            pos += WAVE - popc64(ballot(gt));
+                            sh[c] += gt ? 1u : 0u;
                         }
-                        if (pass && mypos < NCC * WAVE) perm[mypos] = make_uint2(__float_as_uint(kown), sown);
-                        n = (n + mp < cap) ? n + mp : cap;
-                        wave_sync();
-#pragma unroll
-                        for (int c = 0; c < NCC; ++c) {
-                            const uint2 e = perm[c * WAVE + lane];
-                            rk[c] = __uint_as_float(e.x); rv[c] = e.y;
-                        }
-                        if ((uint32_t)((NCC - 1) * WAVE + lane) >= cap) { rk[NCC - 1] = INF; rv[NCC - 1] = FLAG_EXPANDED; }
-                        wave_sync();
-                        worst = (n >= cap) ? readlane_f(rk[NCC - 1], (int)((cap - 1) & 63u)) : INF;
+                        const uint64_t lt = ballot(kj < k), eq = ballot(kj == k) & pm;
+                        pos += popc64(lt | (eq & ((1ull << l) - 1ull)));          // candidates among themselves: list order
+                        if (lane == l) mypos = pos;
                     }
-                    VDB_T_MARK(4);
+#pragma unroll
+                    for (int c = 0; c < NCC; ++c) {
+                        const uint32_t dst = c * WAVE + lane + sh[c];
+                        if (dst < NCC * WAVE) perm[dst] = make_uint2(__float_as_uint(rk[c]), rv[c]);
+                    }
+                    if (pass && mypos < NCC * WAVE) perm[mypos] = make_uint2(__float_as_uint(kj), sj);
+                    n = (n + mp < cap) ? n + mp : cap;
+                    wave_sync();
+#pragma unroll
+                    for (int c = 0; c < NCC; ++c) {
+                        const uint2 e = perm[c * WAVE + lane];
+                        rk[c] = __uint_as_float(e.x); rv[c] = e.y;
+                    }
+                    if ((uint32_t)((NCC - 1) * WAVE + lane) >= cap) { rk[NCC - 1] = INF; rv[NCC - 1] = FLAG_EXPANDED; }
+                    wave_sync();
+                    worst = (n >= cap) ? readlane_f(rk[NCC - 1], (int)((cap - 1) & 63u)) : INF;
                 }
-                if (!visited_room()) return;
-                VDB_T_MARK(5);
+                VDB_T_MARK(4);
+                if (vcount > vlimit || scount > SEC_LIMIT) { room = false; break; }
             }
-            if (cur2 != NONE32 && pf_slot == NONE32) { pf_slot = cur2; pf_word = load_adj_word(gv, cur2); }   // nothing new was scored
+            if (!room) { flags |= QF_HASH_OVERFLOW; break; }
         }
-        // hand the list over in LDS
+        // hand the list over in LDS (Euclidean: root of the squared keys)
 #pragma unroll
         for (int c = 0; c < NCC; ++c) {
             const uint32_t i = c * WAVE + lane;
-            if (i < n) { R.key[i] = rk[c]; R.val[i] = rv[c]; }
+            if (i < n) { R.key[i] = (metric() == VDB_EUCLIDEAN) ? __builtin_sqrtf(rk[c]) : rk[c]; R.val[i] = rv[c]; }
         }
         R.n = n; R.cap = cap;
         wave_sync();
@@ -565,8 +650,10 @@ struct Searcher {
             R.key = reinterpret_cast<float*>(smem); R.val = reinterpret_cast<uint32_t*>(smem) + NCC * WAVE;
             R.key2 = nullptr; R.val2 = nullptr;
             off = (area + 15) & ~(size_t)15;
-            cand = reinterpret_cast<uint32_t*>(smem + off); off += WAVE * 4;
-            craw = reinterpret_cast<float*>(smem + off); off += WAVE * 4;
+            cand = reinterpret_cast<uint32_t*>(smem + off); off += CAND_CAP * 4;
+            craw = reinterpret_cast<float*>(smem + off); off += CAND_CAP * 4;
+            tags.tab = reinterpret_cast<uint32_t*>(smem + off); off += (size_t)2 << a.tag_log2;
+            tags.sec = reinterpret_cast<uint32_t*>(smem + off); off += SEC_IDS * 4;
         } else {
             R.key = reinterpret_cast<float*>(smem + off); off += ef_cap * 4;
             R.val = reinterpret_cast<uint32_t*>(smem + off); off += ef_cap * 4;
@@ -578,16 +665,25 @@ struct Searcher {
                 P.key2 = reinterpret_cast<float*>(smem + off); off += ef_cap * 4;
                 P.val2 = reinterpret_cast<uint32_t*>(smem + off); off += ef_cap * 4;
             }
-            if (NC > 0) { perm = reinterpret_cast<uint2*>(smem + off); off += (size_t)NCC * WAVE * 8; }
-            cand = reinterpret_cast<uint32_t*>(smem + off); off += WAVE * 4;
-            craw = reinterpret_cast<float*>(smem + off); off += WAVE * 4;
+            if (NC > 0) {
+                perm = reinterpret_cast<uint2*>(smem + off); off += (size_t)NCC * WAVE * 8;
+                tags.tab = reinterpret_cast<uint32_t*>(smem + off); off += (size_t)2 << a.tag_log2;
+                tags.sec = reinterpret_cast<uint32_t*>(smem + off); off += SEC_IDS * 4;
+            }
+            cand = reinterpret_cast<uint32_t*>(smem + off); off += CAND_CAP * 4;
+            craw = reinterpret_cast<float*>(smem + off); off += CAND_CAP * 4;
             qlds = reinterpret_cast<float*>(smem + off); off += (size_t)gv.stride * 4;
         }
+        if (NC > 0) {
+            tags.idmask = (1u << (a.tag_log2 + 12)) - 1; tags.smask = SEC_IDS / 4 - 1; tags.sshift = 25;
+            tag_limit = (7u << a.tag_log2) / 10 - 4 * WAVE;                  // room for one more step
+        }
         vis.mask = (1u << (a.hash_log2 - 2)) - 1; vis.shift = 32 - (a.hash_log2 - 2);
-        vis.limit = (1u << a.hash_log2) - (1u << a.hash_log2) / 4 - WAVE;
+        vis.limit = (1u << a.hash_log2) - (1u << a.hash_log2) / 4 - (NC > 0 ? 4 * WAVE : WAVE);   // room for one more step
         vis.tab = reinterpret_cast<uint32_t*>(smem + off);
         vis.spill = nullptr; vis.smask = 0; vis.sshift = 0; vis.scount = 0; vis.slimit = 0; vis.count = 0;
 
+        if (a.only_flagged && !(a.stats[q].flags & QF_HASH_OVERFLOW)) return;      // settled by an earlier launch
         if (lane == 0) a.out_n[q] = 0;
         if (a.entry == NONE32) return;                                     // hnsw.rs:515-518
 #ifdef VDB_TIMING
@@ -618,7 +714,7 @@ struct Searcher {
             uint32_t cur = a.entry;
             for (uint32_t l = a.max_level; l > lvl; --l) cur = greedy(cur, l);          // hnsw.rs:169-173
             for (int l = (int)lvl; l >= 0; --l) {                                       // hnsw.rs:175-199
-                if (l == 0) { if (NC > 0) beam_reg(cur, a.ef); else beam<false, true>(cur, 0, a.ef); }
+                if (l == 0) { if (NC > 0) beam_reg(cur, a.ef, a.beam_width); else beam<false, true>(cur, 0, a.ef); }
                 else beam<false, false>(cur, (uint32_t)l, a.ef);
                 if (flags & QF_HASH_OVERFLOW) break;
                 const uint32_t cnt = R.n < a.m ? R.n : a.m;
@@ -634,7 +730,7 @@ struct Searcher {
             for (uint32_t l = a.max_level; l >= 1; --l) cur = greedy(cur, l);           // hnsw.rs:538-541
             if (MODE == MODE_MASKED) { beam<true, true>(cur, 0, a.ef); if (!(flags & QF_HASH_OVERFLOW)) emit(q, P, false); }
             else {
-                if (NC > 0) beam_reg(cur, a.ef); else beam<false, true>(cur, 0, a.ef);
+                if (NC > 0) beam_reg(cur, a.ef, a.beam_width); else beam<false, true>(cur, 0, a.ef);
                 if (!(flags & QF_HASH_OVERFLOW)) emit(q, R, false);
             }
         }
