@@ -84,7 +84,8 @@ def test_search_same_graph_strict_exact_fast_close(ora, vdb, metric, dim, kind):
     q = data(nq, dim, 99, kind)
     ref, refn, rst = h.search_batch(q, k, with_stats=True)
     for arith in (vdb.Arith.Strict, vdb.Arith.Fast):
-        p = vdb.HNSWIndex(metric, 16, 64, 16, dim, seed=1, arith=arith)
+        # beam_width=1: FAST expands strictly best-first like the reference, so ids must agree
+        p = vdb.HNSWIndex(metric, 16, 64, 16, dim, seed=1, arith=arith, beam_width=1)
         p.import_graph(g)
         got, gotn, st = p.search_batch(q, k, with_stats=True)
         bad = compare_results(ref, refn, got, gotn, exact=(arith == vdb.Arith.Strict))
@@ -99,6 +100,41 @@ def test_search_same_graph_strict_exact_fast_close(ora, vdb, metric, dim, kind):
         p.import_graph(g)
         got, gotn = p.search_batch(q[:50], 20, ef_search=ef)
         compare_results(ref, refn, got, gotn, exact=True)
+
+
+def _recall(ann, ann_n, exact, exact_n, k):
+    hits = 0
+    for a, an, e, en in zip(ann, ann_n, exact, exact_n):
+        hits += len(set(a["id"][:an].tolist()) & set(e["id"][:en].tolist()))
+    return hits / (len(ann) * k)
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("width", [0, 2, 4])
+def test_wide_steps_keep_recall_and_distances(ora, vdb, metric, width):
+    """FAST with several nodes expanded per step (the default): recall@10 within 0.5 pt of the oracle's at equal ef
+    on the same graph, every returned distance within 1e-5 relative of the strict score of that id, lists sorted."""
+    n, d, nq, k = 6000, 64, 300, 10
+    h, x = build_oracle(ora, metric, n, d, seed=31 + metric, kind="clustered")
+    q = data(nq, d, 77, "clustered")
+    exact, exact_n = h.exact_knn_batch(q, k)
+    p = vdb.HNSWIndex(metric, 16, 64, 16, d, seed=1, arith=vdb.Arith.Fast, beam_width=width)
+    p.import_graph(h.export_graph())
+    for ef in (32, 64, 200):
+        ref, refn = h.search_batch(q, k, ef_search=ef)
+        got, gotn, st = p.search_batch(q, k, ef_search=ef, with_stats=True)
+        assert np.array_equal(refn, gotn) and not (st["flags"] & 1).any()
+        r_ref, r_got = _recall(ref, refn, exact, exact_n, k), _recall(got, gotn, exact, exact_n, k)
+        assert r_got >= r_ref - 0.005, (ef, r_ref, r_got)
+        pos = {int(i * 3 + 1): i for i in range(n)}
+        for qi in range(0, nq, 7):
+            ids = got["id"][qi][: gotn[qi]]
+            keys = got["sort_key"][qi][: gotn[qi]]
+            assert np.all(np.diff(keys) >= 0)
+            rows = x[[pos[int(i)] for i in ids]]
+            strict = np.array([ora.score(q[qi], r, metric) for r in rows], np.float32)
+            scale = {0: np.ones(len(ids)), 1: np.linalg.norm(q[qi]) * np.linalg.norm(rows, axis=1), 2: np.abs(strict)}[metric]
+            assert np.all(np.abs(got["raw_score"][qi][: gotn[qi]] - strict) <= 4 * REL * np.maximum(scale, 1e-6))
 
 
 @pytest.mark.parametrize("metric", [0, 1, 2])
