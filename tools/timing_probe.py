@@ -24,8 +24,8 @@ print(f"us per expansion: mean {(life/np.maximum(st['expanded'],1)).mean():.2f}"
 print(f"sum of lifetimes / span = mean resident waves {life.sum()/(start+life).max():.0f}")
 order = np.argsort(start)
 print("start-time deciles (us):", np.percentile(start, [0,10,50,90,99,100]).round(0))
-ph = out.view(np.uint8).reshape(nq, -1)[:, :48].copy().view(np.uint64).astype(np.float64)
-names = ["select+mark", "adjacency", "visited", "score(gather)", "merge", "room"]
+ph = out.view(np.uint8).reshape(nq, -1)[:, :80].copy().view(np.uint64).astype(np.float64)
+names = ["select", "adjacency wait", "compaction", "score(gather)", "merge", "-", "bucket read+classify", "CAS", "resolve+slow path", "-"]
 tot = ph.sum(axis=1)
 print("phase shares of beam cycles (mean over queries):")
 for i, nm in enumerate(names):

@@ -18,7 +18,7 @@ namespace {
 template <int MODE, int G, int CH, int PASSES, bool STRICT, int METRIC, int NC>
 struct Searcher {
 #ifdef VDB_TIMING
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+    unsigned long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
 #endif
     static constexpr int GG = G > 0 ? G : 8, CC = CH > 0 ? CH : 1, PP = PASSES > 0 ? PASSES : 1;
     static constexpr int RPP = WAVE / GG;          // rows one wave instruction covers
@@ -395,6 +395,9 @@ struct Searcher {
 #pragma unroll
             for (int e = 0; e < EMAX; ++e) w[e] = adj0[(size_t)par[(uint32_t)e < np ? e : 0] * ADJ_BLOCK + lane];
             wave_sync();                     // parents are consumed before cand/craw are written again
+#ifdef VDB_TIMING
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // charge the adjacency round trip to its own phase
+#endif
             VDB_T_MARK(1);
             // ---- round 0: the inline neighbours (block words 1..62) of all parents at once; further
             // rounds: one overflow chunk of a high-degree parent each ----
@@ -403,7 +406,7 @@ struct Searcher {
             for (uint32_t round = 0; ; ++round) {
                 int m = 0;
                 if (round == 0) {
-                    uint32_t nb[EMAX], w0[EMAX], tag[EMAX], widx[EMAX], expect[EMAX], desired[EMAX], old[EMAX];
+                    uint32_t nb[EMAX], w0[EMAX], tag[EMAX], widx[EMAX], expect[EMAX], desired[EMAX], old[EMAX], half[EMAX];
                     uint4 bk[EMAX];
                     bool tr[EMAX], fresh[EMAX], slow[EMAX];
 #pragma unroll
@@ -420,20 +423,33 @@ struct Searcher {
                         deg = deg < ADJ_INLINE ? deg : ADJ_INLINE;
                         bool want = (uint32_t)(lane - 1) < deg;                           // words 1..deg hold neighbours
                         if (gv.deleted) want = want && !bit_test(gv.deleted, nb[e]);      // hnsw.rs:475
-                        const bool absent = want && !TagSet::present(bk[e], tag[e]);
+                        const bool pres = TagSet::present(bk[e], tag[e]);
                         const uint32_t u = TagSet::used(bk[e]);
-                        tr[e] = absent && u < 8;
-                        slow[e] = absent && u == 8;                                       // full bucket: generic insert
+                        const bool absent = want & !pres;
+                        tr[e] = absent & (u < 8);
+                        slow[e] = absent & (u == 8);                                      // full bucket: generic insert
                         TagSet::slot_of(bk[e], u, tag[e], widx[e], expect[e], desired[e]);
+                        half[e] = (u & 1u) * 16u;
                     }
+#ifdef VDB_TIMING
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+                    VDB_T_MARK(6);
 #pragma unroll
                     for (int e = 0; e < EMAX; ++e) { old[e] = 0; if (tr[e]) old[e] = atomicCAS(&ts.tab[w0[e] + widx[e]], expect[e], desired[e]); }
+#ifdef VDB_TIMING
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+                    VDB_T_MARK(7);
                     bool any_slow = false;
 #pragma unroll
                     for (int e = 0; e < EMAX; ++e) {
-                        fresh[e] = tr[e] && old[e] == expect[e];
-                        slow[e] = slow[e] || (tr[e] && old[e] != expect[e]);              // the word changed under us
-                        any_slow = any_slow || slow[e];
+                        fresh[e] = tr[e] & (old[e] == expect[e]);
+                        // the word changed under us: if our entry now holds our tag, another lane carried the
+                        // same id (a neighbour shared by two parents) and it counts as visited
+                        const bool same = ((old[e] >> half[e]) & 0xFFFFu) == tag[e];
+                        slow[e] = slow[e] | (tr[e] & (old[e] != expect[e]) & !same);
+                        any_slow = any_slow | slow[e];
                     }
                     if (ballot(any_slow)) {
 #pragma unroll
@@ -446,6 +462,7 @@ struct Searcher {
                             }
                         }
                     }
+                    VDB_T_MARK(8);
 #pragma unroll
                     for (int e = 0; e < EMAX; ++e) {
                         const uint64_t mk = ballot(fresh[e]);
@@ -741,9 +758,9 @@ struct Searcher {
 #ifdef VDB_TIMING
         // diagnostic build only: adj_entries carries the wavefront's lifetime in 10 ns ticks, rows_scored its start tick
         adj_entries = (uint32_t)(wall_clock64() - t_begin); rows_scored = (uint32_t)t_begin;
-        if (lane == 0 && a.out && a.top_k >= 4) {      // phase totals overwrite this query's result records
+        if (lane == 0 && a.out && a.top_k >= 5) {      // phase totals overwrite this query's result records
             unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.out + (size_t)q * a.top_k);
-            for (int i = 0; i < 6; ++i) dbg[i] = tacc[i];
+            for (int i = 0; i < 10; ++i) dbg[i] = tacc[i];
         }
 #endif
         // on a filter error `expanded` carries the slot whose evaluation failed
@@ -764,7 +781,7 @@ __global__ void __launch_bounds__(64) search_kernel(SearchArgs a) {
 template <int MODE, int METRIC, int NC>
 void launch_search_shape(const SearchArgs& a, size_t lds, hipStream_t st) {
     const uint32_t chunks = a.g.stride / 4;
-    constexpr int P8 = NC > 0 ? 2 : 4;             // row groups in flight per lane for short rows
+    constexpr int P8 = NC > 0 ? 3 : 4;             // row groups in flight per lane for short rows
     if (chunks <= 32) hipLaunchKernelGGL((search_kernel<MODE, 8, 4, P8, false, METRIC, NC>), dim3(a.nq), dim3(64), lds, st, a);
     else if (chunks <= 256) hipLaunchKernelGGL((search_kernel<MODE, 64, 4, 8, false, METRIC, NC>), dim3(a.nq), dim3(64), lds, st, a);
     else if (chunks <= 512) hipLaunchKernelGGL((search_kernel<MODE, 64, 8, 4, false, METRIC, NC>), dim3(a.nq), dim3(64), lds, st, a);
