@@ -141,7 +141,7 @@ def main():
 
     # ---- ef sweep ----
     sweep = {}
-    efs = [args.ef] if args.ef else [16, 24, 32, 48, 64, 96, 128, 192, 256]
+    efs = [args.ef] if args.ef else [16, 32, 64, 96, 128, 144, 160, 176, 192, 224, 256]
     chosen = None
     for ef in efs:
         search(ef); stream.synchronize()
@@ -246,7 +246,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("hbm_bytes_per_launch") if tj.get("ef_search", ef) == ef else None
             except Exception:
                 traffic = None
         result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

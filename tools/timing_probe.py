@@ -26,6 +26,8 @@ order = np.argsort(start)
 print("start-time deciles (us):", np.percentile(start, [0,10,50,90,99,100]).round(0))
 ph = out.view(np.uint8).reshape(nq, -1)[:, :80].copy().view(np.uint64).astype(np.float64)
 names = ["select", "adjacency wait", "compaction", "score(gather)", "merge", "-", "bucket read+classify", "CAS", "resolve+slow path", "-"]
+print(f"before the beam (query load, upper-layer descent): mean {ph[:, 9].mean()*0.01:.1f} us of {ph[:, 5].mean()*0.01:.1f} us per query")
+ph[:, 9] = 0; ph[:, 5] = 0
 tot = ph.sum(axis=1)
 print("phase shares of beam cycles (mean over queries):")
 for i, nm in enumerate(names):

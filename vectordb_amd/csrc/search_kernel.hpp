@@ -370,6 +370,7 @@ struct Searcher {
         wave_sync();
 #ifdef VDB_TIMING
         tlast = clock64();
+        tacc[9] = wall_clock64();            // beam start (100 MHz ticks)
 #endif
         for (;;) {
             // ---- the `width` best unexpanded entries, in list order: rank by ballot, ids through LDS ----
@@ -760,6 +761,7 @@ struct Searcher {
         adj_entries = (uint32_t)(wall_clock64() - t_begin); rows_scored = (uint32_t)t_begin;
         if (lane == 0 && a.out && a.top_k >= 5) {      // phase totals overwrite this query's result records
             unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.out + (size_t)q * a.top_k);
+            tacc[9] -= t_begin; tacc[5] = wall_clock64() - t_begin;
             for (int i = 0; i < 10; ++i) dbg[i] = tacc[i];
         }
 #endif
