@@ -158,6 +158,23 @@ void vdb_index::sync_device() {
                 pool.insert(pool.end(), tmp.begin(), tmp.end());
             }
         }
+        // fused upper-layer blocks (see GraphView::ublk); skipped when the packed reference cannot hold the counts
+        std::vector<uint32_t> ublk, ublk_ref;
+        have_ublk = udesc.size() < (size_t(1) << UREF_BITS);
+        for (uint32_t s = 0; s < n && have_ublk; ++s) if (upper_cnt[s] > 63) have_ublk = false;
+        if (have_ublk) {
+            ublk.assign(udesc.size() * ADJ_BLOCK, 0); ublk_ref.assign(udesc.size() * ADJ_BLOCK, 0);
+            for (size_t d = 0; d < udesc.size(); ++d) {
+                const uint64_t off = udesc[d] & 0xFFFFFFFFFFull; const uint32_t deg = (uint32_t)(udesc[d] >> 40);
+                uint32_t* blk = &ublk[d * ADJ_BLOCK]; uint32_t* ref = &ublk_ref[d * ADJ_BLOCK];
+                blk[0] = deg; blk[63] = (uint32_t)(off + ADJ_INLINE);
+                for (uint32_t i = 0; i < std::min<uint32_t>(deg, ADJ_INLINE); ++i) {
+                    const uint32_t nb = pool[off + i];
+                    blk[1 + i] = nb; ref[1 + i] = make_uref(upper_base[nb], upper_cnt[nb]);
+                }
+            }
+            if (pool.size() >= (size_t(1) << 32)) have_ublk = false;
+        }
         l0_edges = l0_edges_acc; l0_edges_acc = 0; upper_edges = pool.size();
         const size_t n1 = std::max<size_t>(n, 1);
         d_adj0.reserve(n1 * ADJ_BLOCK, stream, false); d_ovf.reserve(std::max<size_t>(ovf.size(), 1), stream, false);
@@ -171,8 +188,13 @@ void vdb_index::sync_device() {
         if (!ovf.empty()) VDB_HIP(hipMemcpyAsync(d_ovf.p, ovf.data(), ovf.size() * 4, hipMemcpyHostToDevice, stream));
         if (!udesc.empty()) VDB_HIP(hipMemcpyAsync(d_udesc.p, udesc.data(), udesc.size() * 8, hipMemcpyHostToDevice, stream));
         if (!pool.empty()) VDB_HIP(hipMemcpyAsync(d_pool.p, pool.data(), pool.size() * 4, hipMemcpyHostToDevice, stream));
+        if (have_ublk && !ublk.empty()) {
+            d_ublk.reserve(ublk.size(), stream, false); d_ublk_ref.reserve(ublk_ref.size(), stream, false);
+            VDB_HIP(hipMemcpyAsync(d_ublk.p, ublk.data(), ublk.size() * 4, hipMemcpyHostToDevice, stream));
+            VDB_HIP(hipMemcpyAsync(d_ublk_ref.p, ublk_ref.data(), ublk_ref.size() * 4, hipMemcpyHostToDevice, stream));
+        }
         VDB_HIP(hipStreamSynchronize(stream));
-        device_bytes = n * (size_t)stride * 4 + n * 8 + adj0.size() * 4 + ovf.size() * 4 + n * 5 + udesc.size() * 8 + pool.size() * 4;
+        device_bytes = n * (size_t)stride * 4 + n * 8 + adj0.size() * 4 + ovf.size() * 4 + n * 5 + udesc.size() * 8 + pool.size() * 4 + (have_ublk ? ublk.size() * 8 : 0);
         graph_dirty = false;
     }
     if (deleted_dirty) {
@@ -191,7 +213,7 @@ GraphView vdb_index::view() const {
     GraphView g{};
     g.vecs = d_vecs.p; g.stride = stride; g.dim = (uint32_t)dim; g.n = (uint32_t)ids.size();
     g.ids = d_ids.p; g.adj0 = d_adj0.p; g.ovf = d_ovf.p; g.upper_base = d_upper_base.p; g.upper_cnt = d_upper_cnt.p;
-    g.udesc = d_udesc.p; g.pool = d_pool.p; g.deleted = n_deleted ? d_deleted.p : nullptr; g.metric = (int)metric;
+    g.udesc = d_udesc.p; g.pool = d_pool.p; g.ublk = have_ublk ? d_ublk.p : nullptr; g.ublk_ref = have_ublk ? d_ublk_ref.p : nullptr; g.deleted = n_deleted ? d_deleted.p : nullptr; g.metric = (int)metric;
     return g;
 }
 

@@ -63,7 +63,8 @@ struct vdb_index {
     // device state
     hipStream_t stream = nullptr;
     vdb::DevBuf<float> d_vecs; vdb::DevBuf<uint64_t> d_ids, d_udesc;
-    vdb::DevBuf<uint32_t> d_adj0, d_ovf, d_upper_base, d_pool, d_deleted; vdb::DevBuf<uint8_t> d_upper_cnt;
+    vdb::DevBuf<uint32_t> d_adj0, d_ovf, d_upper_base, d_pool, d_deleted, d_ublk, d_ublk_ref;
+    bool have_ublk = false; vdb::DevBuf<uint8_t> d_upper_cnt;
     size_t rows_on_device = 0; bool graph_dirty = true, deleted_dirty = true;
     size_t l0_edges = 0, upper_edges = 0, device_bytes = 0, l0_edges_acc = 0;
     // per-call scratch (guarded by mu)

@@ -12,6 +12,8 @@ constexpr uint32_t ADJ_BLOCK = 64;         // dwords per layer-0 adjacency block
 constexpr uint32_t ADJ_INLINE = 62;        // neighbours held in the block itself
 // Packed adjacency descriptor: low 40 bits = first index into the neighbour pool, high 24 = degree.
 __host__ __device__ inline uint64_t make_desc(uint64_t off, uint32_t deg) { return off | ((uint64_t)deg << 40); }
+constexpr uint32_t UREF_BITS = 26;         // packed upper reference: low 26 bits first descriptor, high 6 bits list count
+__host__ __device__ inline uint32_t make_uref(uint32_t base, uint32_t cnt) { return cnt ? (base | (cnt << UREF_BITS)) : 0u; }
 
 // Read-only view of the device-resident graph handed to every kernel.
 struct GraphView {
@@ -24,6 +26,11 @@ struct GraphView {
     const uint8_t* upper_cnt;   // per slot: lists owned at layers 1..upper_cnt
     const uint64_t* udesc;
     const uint32_t* pool;       // upper layers: neighbour slots (all lists: self-loops and duplicates removed)
+    // Fused upper-layer blocks, one per descriptor (index upper_base[slot] + level - 1), or nullptr:
+    // ublk: 64 dwords [degree, first 62 neighbours, pool index of the 63rd]; ublk_ref: for the
+    // neighbour in the same word its packed (upper_base | upper_cnt << 26), so a greedy move needs
+    // no look-up before the next block can be requested.
+    const uint32_t* ublk; const uint32_t* ublk_ref;
     const uint32_t* deleted;    // bitmap (1 = tombstone) or nullptr when nothing is deleted
     int metric;
 };

@@ -133,6 +133,59 @@ struct Searcher {
         return cur;
     }
 
+    // greedy() on the fused upper-layer blocks: a move costs two dependent round trips (the node's
+    // block, then the rows of its neighbours) because every neighbour carries the reference of its
+    // own blocks.  `ref` is the packed reference of `cur` and follows it; the key of `cur` is
+    // carried from level to level.  Same moves as greedy(): the first improving neighbour in list
+    // order, at most 1000 steps per level.
+    __device__ __forceinline__ uint32_t greedy_fused(uint32_t cur, uint32_t& ref, uint32_t level, float& kcur, bool& have_cur) {
+        const int lane = lane_id();
+        bool changed = true; int steps = 0;
+        while (changed && steps < 1000) {
+            ++steps; changed = false;
+            if (level > (ref >> UREF_BITS)) break;                               // no list at this level
+            const size_t blk = ((size_t)(ref & ((1u << UREF_BITS) - 1u)) + level - 1) * ADJ_BLOCK;
+            const uint32_t w = gv.ublk[blk + lane], wr = gv.ublk_ref[blk + lane];
+            const uint32_t deg = readlane_u(w, 0);
+            if (deg == 0) break;
+            ++expanded; adj_entries += deg;
+            const uint32_t nchunks = deg <= ADJ_INLINE ? 1u : 1u + (deg - ADJ_INLINE + 63u) / 64u;
+            const uint32_t* rest = gv.pool + readlane_u(w, 63);
+            for (uint32_t c = 0; c < nchunks && !changed; ++c) {
+                uint32_t nb, nr; bool in;
+                if (c == 0) { nb = w; nr = wr; in = (uint32_t)(lane - 1) < (deg < ADJ_INLINE ? deg : ADJ_INLINE); }
+                else {
+                    const uint32_t i = (c - 1) * 64u + lane;
+                    in = ADJ_INLINE + i < deg;
+                    nb = in ? rest[i] : 0u;
+                    nr = in ? make_uref(gv.upper_base[nb], gv.upper_cnt[nb]) : 0u;
+                }
+                const bool ok = in && !is_deleted(nb);
+                const uint64_t mk = ballot(ok);
+                const int m = popc64(mk);
+                if (m == 0) continue;
+                const uint32_t rnk = rank_below(mk);
+                if (ok) cand[rnk] = nb;
+                const bool with_cur = !have_cur && m < WAVE;                      // score `cur` in the same pass
+                if (!have_cur && !with_cur) { kcur = key_of(score_one(cur)); have_cur = true; if (ok) cand[rnk] = nb; }
+                if (with_cur && lane == 0) cand[m] = cur;
+                wave_sync();
+                score(with_cur ? m + 1 : m);
+                if (with_cur) { kcur = key_of(craw[m]); have_cur = true; }
+                const float kl = lane < m ? key_of(craw[lane]) : 0.f;
+                const uint64_t bm = ballot(lane < m && kl < kcur);
+                if (bm) {
+                    const int j = __ffsll((unsigned long long)bm) - 1;
+                    const uint64_t src = ballot(ok && rnk == (uint32_t)j);       // the lane that holds candidate j
+                    const int sl = __ffsll((unsigned long long)src) - 1;
+                    cur = readlane_u(nb, sl); ref = readlane_u(nr, sl); kcur = readlane_f(kl, j); changed = true;
+                }
+                wave_sync();
+            }
+        }
+        return cur;
+    }
+
     // hnsw.rs:370-418: scan the WHOLE list keeping the best filter-passing neighbour (strict <, so
     // the first of equal minima wins), repeat until a scan makes no move; no step cap.  A
     // neighbour whose filter evaluation is an Err aborts the search (hnsw.rs:392).
@@ -730,6 +783,10 @@ struct Searcher {
         } else if (MODE == MODE_BUILD) {
             const uint32_t lvl = a.q_levels[q];
             uint32_t cur = a.entry;
+            if (gv.ublk) {
+                uint32_t ref = make_uref(gv.upper_base[cur], gv.upper_cnt[cur]); float kc = 0.f; bool hc = false;
+                for (uint32_t l = a.max_level; l > lvl; --l) cur = greedy_fused(cur, ref, l, kc, hc);
+            } else
             for (uint32_t l = a.max_level; l > lvl; --l) cur = greedy(cur, l);          // hnsw.rs:169-173
             for (int l = (int)lvl; l >= 0; --l) {                                       // hnsw.rs:175-199
                 if (l == 0) { if (NC > 0) beam_reg(cur, a.ef, a.beam_width); else beam<false, true>(cur, 0, a.ef); }
@@ -745,6 +802,10 @@ struct Searcher {
             if (a.out && !(flags & QF_HASH_OVERFLOW)) emit(q, R, false);                // layer-0 beam, full list
         } else {
             uint32_t cur = a.entry;
+            if (gv.ublk) {
+                uint32_t ref = make_uref(gv.upper_base[cur], gv.upper_cnt[cur]); float kc = 0.f; bool hc = false;
+                for (uint32_t l = a.max_level; l >= 1; --l) cur = greedy_fused(cur, ref, l, kc, hc);
+            } else
             for (uint32_t l = a.max_level; l >= 1; --l) cur = greedy(cur, l);           // hnsw.rs:538-541
             if (MODE == MODE_MASKED) { beam<true, true>(cur, 0, a.ef); if (!(flags & QF_HASH_OVERFLOW)) emit(q, P, false); }
             else {
