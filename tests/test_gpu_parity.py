@@ -179,6 +179,32 @@ def test_exact_knn_bit_exact(ora, vdb, metric):
     assert not (set(got["id"].ravel().tolist()) & deleted_ids)
 
 
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("dim", [3, 32, 100, 128, 200])
+def test_exact_knn_matrix_core_pass_matches_brute_force(ora, vdb, metric, dim):
+    """FAST exact k-NN (MFMA candidate pass + strict re-rank) against the oracle's brute force: same ids, same bits,
+    over several chunks and query blocks, with tombstones and repeated rows; STRICT index gives the same answer."""
+    n, nq, k = 20000, 300, 10
+    kind = "clustered" if dim >= 100 else "uniform"
+    xs = data(n, dim, 50 + dim, kind)
+    xs[1000:1008] = xs[7]                                     # repeated rows: exact ties, ordered by id
+    if metric == 0:
+        xs = xs / np.maximum(np.linalg.norm(xs, axis=1, keepdims=True), 1e-20).astype(np.float32)
+    ids = (np.arange(n, dtype=np.uint64)[::-1] * 3 + 1).copy()  # ids descend with the slot
+    dele = np.zeros(n, np.uint8); dele[::13] = 1
+    g = dict(ids=ids, levels=np.zeros(n, np.uint32), vectors=xs, deleted=dele, layers=[], entry=int(ids[1]), current_max_level=0)
+    q = data(nq, dim, 51, kind); q[0] = xs[7]
+    ho = ora.HNSWIndex(metric, 16, 64, 16, dim); ho.import_graph(g)
+    ref, refn = ho.exact_knn_batch(q, k)
+    for arith in (vdb.Arith.Fast, vdb.Arith.Strict):
+        hp = vdb.HNSWIndex(metric, 16, 64, 16, dim, arith=arith); hp.import_graph(g)
+        got, gotn = hp.exact_knn_batch(q, k)
+        assert np.array_equal(refn, gotn)
+        assert np.array_equal(ref["id"], got["id"]), (arith, np.argwhere(ref["id"] != got["id"])[:5])
+        assert np.array_equal(ref["raw_score"].view(np.uint32), got["raw_score"].view(np.uint32))
+        assert np.array_equal(ref["sort_key"].view(np.uint32), got["sort_key"].view(np.uint32))
+
+
 def test_exact_knn_ties_break_by_id(ora, vdb):
     d = 8
     base = np.zeros((40, d), np.float32); base[:, 0] = np.repeat(np.arange(10), 4)     # 4-way exact ties

@@ -365,12 +365,20 @@ void vdb_index::exact_knn(const float* q, size_t nq, size_t top_k, bool dev, vdb
     use_device();
     if (!s) s = stream;
     sync_device();
+    const GraphView g = view();
+    // FAST: MFMA candidate pass + strict re-rank; STRICT (and shapes the MFMA kernel does not take): every pair in strict arithmetic
+    const bool mfma = opts.arith == VDB_ARITH_FAST && knn_mfma_supported(g, (uint32_t)top_k) && !std::getenv("VDB_KNN_STRICT");
     const uint32_t chunks = exact_knn_chunks((uint32_t)ids.size());
-    s_knn.reserve(nq * chunks * top_k, s, false);
-    if (dev) { launch_exact_knn(view(), q, (uint32_t)nq, (uint32_t)top_k, out, out_n, s_knn.p, chunks, s); return; }
+    if (mfma) s_knn_words.reserve(knn_mfma_scratch_words(g.n, (uint32_t)nq), s, false);
+    else s_knn.reserve(nq * chunks * top_k, s, false);
+    auto run = [&](const float* dq, vdb_scored_point* dout, uint32_t* dn) {
+        if (mfma) launch_exact_knn_mfma(g, dq, (uint32_t)nq, (uint32_t)top_k, dout, dn, s_knn_words.p, s);
+        else launch_exact_knn(g, dq, (uint32_t)nq, (uint32_t)top_k, dout, dn, s_knn.p, chunks, s);
+    };
+    if (dev) { run(q, out, out_n); return; }
     s_q.reserve(nq * dim, s, false); s_out.reserve(nq * top_k, s, false); s_n.reserve(nq, s, false);
     VDB_HIP(hipMemcpyAsync(s_q.p, q, nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
-    launch_exact_knn(view(), s_q.p, (uint32_t)nq, (uint32_t)top_k, s_out.p, s_n.p, s_knn.p, chunks, s);
+    run(s_q.p, s_out.p, s_n.p);
     VDB_HIP(hipMemcpyAsync(out, s_out.p, nq * top_k * sizeof(vdb_scored_point), hipMemcpyDeviceToHost, s));
     VDB_HIP(hipMemcpyAsync(out_n, s_n.p, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     VDB_HIP(hipStreamSynchronize(s));

@@ -95,6 +95,11 @@ void launch_normalize_rows(float* vecs, uint32_t stride, uint32_t dim, uint32_t 
 void launch_exact_knn(const GraphView& g, const float* queries, uint32_t nq, uint32_t top_k, vdb_scored_point* out, uint32_t* out_n,
                       vdb_scored_point* scratch, uint32_t n_chunks, hipStream_t s);
 uint32_t exact_knn_chunks(uint32_t n);
+// FAST exact k-NN: fp32 MFMA candidate pass + strict re-rank (knn_mfma.hip).  scratch holds knn_mfma_scratch_words() dwords.
+bool knn_mfma_supported(const GraphView& g, uint32_t top_k);
+size_t knn_mfma_scratch_words(uint32_t n, uint32_t nq);
+void launch_exact_knn_mfma(const GraphView& g, const float* queries, uint32_t nq, uint32_t top_k, vdb_scored_point* out, uint32_t* out_n,
+                           uint32_t* scratch, hipStream_t s);
 void launch_topk_merge(const vdb_scored_point* lists, const uint32_t* counts, uint32_t n_shards, uint32_t nq, uint32_t k,
                        vdb_scored_point* out, uint32_t* out_n, hipStream_t s);
 

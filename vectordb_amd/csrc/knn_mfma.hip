@@ -1,0 +1,286 @@
+// Exact k-NN, FAST arithmetic: a dense fp32 MFMA contraction (queries x base rows) with a fused
+// top-k' epilogue selects candidates, then every candidate is re-scored with the STRICT
+// arithmetic (metric.rs:15-35, one lane per row, sequential sums) and ranked by (sort_key, id), so
+// the returned keys are the strict ones bit for bit.  The candidate pass keeps, per query and per
+// chunk of the base set, the KNN_KP rows with the smallest *ranking key* (L2: |x|^2 - 2 q.x, dot:
+// -q.x, cosine: -q.x / |x|); it misses a true neighbour only if more than KNN_KP - top_k rows of
+// one chunk fall within the fp32 rounding error of the contraction (~1e-6 relative) of it.
+#include "device_common.hpp"
+#include <algorithm>
+
+namespace vdb {
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int MQ = 128;            // queries per block: 4 waves x 32 (the N side of the 32x32 tile)
+constexpr int MT = 32;             // base rows per tile (the M side)
+constexpr int KNN_KP = 24;         // candidates kept per (query, chunk)
+constexpr int KNN_CAP = 56;        // per-query buffer: KNN_KP kept + room for one tile of pushes (32)
+constexpr float INF_F = __builtin_inff();
+
+// scale / bias turn a dot product into the ranking key: key = dot * scale[row] + bias[row].
+__global__ void __launch_bounds__(256) knn_prepare_kernel(GraphView gv, float* __restrict__ scale, float* __restrict__ bias) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= gv.n) return;
+    const float* row = gv.vecs + (size_t)r * gv.stride;
+    float s = 0.f;
+    for (uint32_t d = 0; d < gv.dim; ++d) s = __builtin_fmaf(row[d], row[d], s);
+    float sc, bi = 0.f;
+    if (gv.metric == VDB_EUCLIDEAN) { sc = -2.f; bi = s; }
+    else if (gv.metric == VDB_DOT) sc = -1.f;
+    else sc = s > 0.f ? -1.0f / __builtin_sqrtf(s) : 0.f;
+    if (gv.deleted && bit_test(gv.deleted, r)) { sc = 0.f; bi = INF_F; }
+    scale[r] = sc; bias[r] = bi;
+}
+
+// grid (n_chunks, ceil(nq / MQ)), 256 threads.  KH = k-steps of the 32x32x2 MFMA = padded row / 2;
+// k-step s of lane half h multiplies dimension h*KH + s, so a lane reads KH contiguous floats.
+template <int KH>
+__global__ void __launch_bounds__(256) knn_mfma_kernel(GraphView gv, const float* __restrict__ queries, uint32_t nq,
+                                                      const float* __restrict__ scale, const float* __restrict__ bias,
+                                                      uint32_t* __restrict__ out_slots, uint32_t n_chunks) {
+    constexpr int K = 2 * KH, LDA = K + 4;                     // padded tile row: conflict-free 16-byte reads
+    constexpr int VPT = K / 32;                                // float4 per thread per tile (256 threads, 32 rows)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* At = reinterpret_cast<float*>(smem);                                  // MT x LDA
+    float* sc_t = At + MT * LDA;                                                 // MT
+    float* bi_t = sc_t + MT;                                                     // MT
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(bi_t + MT);                      // MQ
+    uint2* buf = reinterpret_cast<uint2*>(cnt + MQ);                             // MQ x KNN_CAP {key bits, row}
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const uint32_t stride = gv.stride, dim = gv.dim;
+    const uint32_t q = blockIdx.y * MQ + wave * 32 + j;        // this lane's query (two lanes per query)
+    const uint32_t ql = wave * 32 + j;                         // its index within the block
+
+    // B operand: the whole query stays in registers
+    float b[KH];
+#pragma unroll
+    for (int s = 0; s < KH; ++s) {
+        const uint32_t d = h * KH + s;
+        b[s] = (q < nq && d < dim) ? queries[(size_t)q * dim + d] : 0.f;
+    }
+    if (tid < MQ) cnt[tid] = 0;
+    float thr = INF_F;
+
+    const uint32_t per = (((gv.n + n_chunks - 1) / n_chunks) + MT - 1) / MT * MT;
+    const uint32_t r_begin = blockIdx.x * per, r_end = min(gv.n, r_begin + per);
+    // loader: thread t brings columns [part*K/8, +K/8) of tile row t/8
+    const int lrow = tid >> 3, lpart = tid & 7;
+    float4 stage[VPT];
+    float st_sc = 0.f, st_bi = INF_F;
+    auto fetch = [&](uint32_t tile_base) {
+        const uint32_t r = tile_base + lrow;
+        const bool in = r < r_end;
+        const float* row = gv.vecs + (size_t)(in ? r : r_begin) * stride;
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            const uint32_t c = lpart * (K / 8) + v * 4;
+            stage[v] = (in && c < stride) ? *reinterpret_cast<const float4*>(row + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (tid < MT) { const uint32_t rr = tile_base + tid; st_sc = rr < r_end ? scale[rr] : 0.f; st_bi = rr < r_end ? bias[rr] : INF_F; }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) *reinterpret_cast<float4*>(At + lrow * LDA + lpart * (K / 8) + v * 4) = stage[v];
+        if (tid < MT) { sc_t[tid] = st_sc; bi_t[tid] = st_bi; }
+    };
+
+    // keeps the KNN_KP smallest (key, row) of query `qi`'s buffer; all lanes of the wave take part
+    auto compact = [&](uint32_t qi) -> float {
+        const uint32_t n = __builtin_amdgcn_readfirstlane(cnt[qi]);
+        uint2 e = make_uint2(0x7f800000u, 0xFFFFFFFFu);
+        if ((uint32_t)lane < n) e = buf[qi * KNN_CAP + lane];
+        const float k = __uint_as_float(e.x);
+        uint32_t rank = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const float ki = readlane_f(k, (int)i); const uint32_t ri = readlane_u(e.y, (int)i);
+            rank += (ki < k || (ki == k && ri < e.y)) ? 1u : 0u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if ((uint32_t)lane < n && rank < KNN_KP) buf[qi * KNN_CAP + rank] = e;
+        const uint32_t kept = n < KNN_KP ? n : KNN_KP;
+        if (lane == 0) cnt[qi] = kept;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // new threshold: the largest kept key once KNN_KP are held
+        const uint64_t last = __ballot((uint32_t)lane < n && rank == KNN_KP - 1);
+        return last ? readlane_f(k, __ffsll((unsigned long long)last) - 1) : INF_F;
+    };
+
+    if (r_begin < r_end) fetch(r_begin);
+    for (uint32_t tb = r_begin; tb < r_end; tb += MT) {
+        __syncthreads();                           // the previous tile has been consumed
+        stash();
+        __syncthreads();
+        if (tb + MT < r_end) fetch(tb + MT);       // in flight during the contraction
+        floatx16 acc;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+        const float* arow = At + j * LDA + h * KH;
+#pragma unroll
+        for (int c = 0; c < KH / 4; ++c) {
+            const float4 a4 = *reinterpret_cast<const float4*>(arow + 4 * c);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b[4 * c + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b[4 * c + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b[4 * c + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b[4 * c + 3], acc, 0, 0, 0);
+        }
+        // epilogue: acc[v] = q_j . x_i with i = (v/4)*8 + h*4 + v%4
+        float key[16];
+        bool any = false;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 s4 = *reinterpret_cast<const float4*>(sc_t + g4 * 8 + h * 4);
+            const float4 b4 = *reinterpret_cast<const float4*>(bi_t + g4 * 8 + h * 4);
+            key[g4 * 4 + 0] = __builtin_fmaf(acc[g4 * 4 + 0], s4.x, b4.x);
+            key[g4 * 4 + 1] = __builtin_fmaf(acc[g4 * 4 + 1], s4.y, b4.y);
+            key[g4 * 4 + 2] = __builtin_fmaf(acc[g4 * 4 + 2], s4.z, b4.z);
+            key[g4 * 4 + 3] = __builtin_fmaf(acc[g4 * 4 + 3], s4.w, b4.w);
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) any = any || key[v] < thr;
+        if (q >= nq) any = false;
+        if (__ballot(any)) {
+            if (any) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    if (key[v] < thr) {
+                        const uint32_t pos = atomicAdd(&cnt[ql], 1u);
+                        buf[ql * KNN_CAP + pos] = make_uint2(__float_as_uint(key[v]), tb + (v / 4) * 8 + h * 4 + (v % 4));
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            // queries of this wave whose buffer could not take another tile
+            uint64_t need = __ballot(lane < 32 && cnt[wave * 32 + (lane & 31)] > KNN_KP);
+            while (need) {
+                const int jj = __ffsll((unsigned long long)need) - 1; need &= need - 1;
+                const float nt = compact(wave * 32 + jj);
+                if (j == jj) thr = nt;
+            }
+        }
+    }
+    // hand over: KNN_KP slots per (query, chunk), NONE32 marks unused entries
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int jj = 0; jj < 32; ++jj) {
+        const uint32_t qi = wave * 32 + jj, qg = blockIdx.y * MQ + qi;
+        if (qg >= nq) break;
+        if (cnt[qi] > KNN_KP) compact(qi);
+        const uint32_t n = cnt[qi];
+        if (lane < KNN_KP) out_slots[((size_t)qg * n_chunks + blockIdx.x) * KNN_KP + lane] = (uint32_t)lane < n ? buf[qi * KNN_CAP + lane].y : NONE32;
+    }
+}
+
+// One wave per query: strict scores of the candidate slots, ranked by (sort_key, id).
+struct TopKList {
+    float* key; uint64_t* id; float* raw; uint32_t n, cap;
+    __device__ bool admits(float k, uint64_t i) const {
+        if (n < cap) return true;
+        const float wk = key[cap - 1];
+        return k < wk || (k == wk && i < id[cap - 1]);
+    }
+    __device__ void insert(float k, uint64_t idv, float rawv) {
+        const int lane = lane_id();
+        uint32_t pos = 0;
+        for (uint32_t b = 0; b < n; b += WAVE) {
+            const uint32_t i = b + lane;
+            pos += popc64(ballot(i < n && (key[i] < k || (key[i] == k && id[i] < idv))));
+        }
+        const uint32_t last = (n < cap) ? n : cap - 1;
+        for (int b = (int)(last & ~63u); b >= (int)(pos & ~63u); b -= WAVE) {
+            const uint32_t i = (uint32_t)b + lane;
+            const bool mv = i > pos && i <= last;
+            float tk = 0.f, tr = 0.f; uint64_t ti = 0;
+            if (mv) { tk = key[i - 1]; ti = id[i - 1]; tr = raw[i - 1]; }
+            wave_sync();
+            if (mv) { key[i] = tk; id[i] = ti; raw[i] = tr; }
+            wave_sync();
+        }
+        if (lane == 0) { key[pos] = k; id[pos] = idv; raw[pos] = rawv; }
+        if (n < cap) ++n;
+        wave_sync();
+    }
+};
+
+__global__ void __launch_bounds__(64) knn_rerank_kernel(GraphView gv, const float* __restrict__ queries, uint32_t top_k,
+                                                       const uint32_t* __restrict__ slots, uint32_t per_query,
+                                                       vdb_scored_point* __restrict__ out, uint32_t* __restrict__ out_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = lane_id();
+    const uint32_t q = blockIdx.x, dim = gv.dim, stride = gv.stride;
+    float* ql = reinterpret_cast<float*>(smem);
+    uint64_t* lid = reinterpret_cast<uint64_t*>(smem + (size_t)stride * 4);
+    float* lkey = reinterpret_cast<float*>(lid + top_k);
+    float* lraw = lkey + top_k;
+    for (uint32_t i = lane; i < stride; i += WAVE) ql[i] = i < dim ? queries[(size_t)q * dim + i] : 0.f;
+    wave_sync();
+    if (gv.metric == VDB_COSINE) {                                            // hnsw.rs:526-536, 752-764
+        float s = -0.0f;
+        for (uint32_t i = 0; i < dim; ++i) { float p = ql[i] * ql[i]; s = s + p; }
+        const float norm = __builtin_sqrtf(s);
+        wave_sync();
+        if (norm != 0.0f) for (uint32_t i = lane; i < dim; i += WAVE) ql[i] = ql[i] / norm;
+        wave_sync();
+    }
+    TopKList L{lkey, lid, lraw, 0, top_k};
+    for (uint32_t b = 0; b < per_query; b += WAVE) {
+        const uint32_t i = b + lane;
+        const uint32_t s = i < per_query ? slots[(size_t)q * per_query + i] : NONE32;
+        const bool valid = s != NONE32;
+        float raw = 0.f; uint64_t idv = 0;
+        if (valid) { raw = strict_pair(ql, gv.vecs + (size_t)s * stride, dim, gv.metric, true); idv = gv.ids[s]; }
+        const float k = gv.metric == VDB_DOT ? -raw : raw;
+        uint64_t am = ballot(valid && L.admits(k, idv));
+        while (am) {
+            const int jj = __ffsll((unsigned long long)am) - 1; am &= am - 1;
+            const float kk = readlane_f(k, jj), rr = readlane_f(raw, jj);
+            const uint64_t ii = ((uint64_t)readlane_u((uint32_t)(idv >> 32), jj) << 32) | readlane_u((uint32_t)idv, jj);
+            if (!L.admits(kk, ii)) continue;
+            L.insert(kk, ii, rr);
+        }
+    }
+    for (uint32_t i = lane; i < L.n; i += WAVE) { vdb_scored_point sp; sp.id = lid[i]; sp.raw_score = lraw[i]; sp.sort_key = lkey[i]; out[(size_t)q * top_k + i] = sp; }
+    if (lane == 0) out_n[q] = L.n;
+}
+
+template <int KH>
+void launch_mfma(const GraphView& g, const float* queries, uint32_t nq, const float* scale, const float* bias, uint32_t* slots,
+                 uint32_t n_chunks, hipStream_t st) {
+    constexpr int K = 2 * KH;
+    const size_t lds = (size_t)MT * (K + 4) * 4 + 2 * MT * 4 + MQ * 4 + (size_t)MQ * KNN_CAP * 8;
+    hipLaunchKernelGGL((knn_mfma_kernel<KH>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, queries, nq, scale, bias, slots, n_chunks);
+}
+
+}  // namespace
+
+bool knn_mfma_supported(const GraphView& g, uint32_t top_k) { return top_k >= 1 && top_k <= 16 && g.stride <= 256 && g.n > 0; }
+uint32_t knn_mfma_chunks(uint32_t n, uint32_t nq) {
+    // enough blocks to fill 256 CUs several times over, chunks of at least 4096 rows
+    const uint32_t qblocks = (nq + MQ - 1) / MQ;
+    uint32_t c = (2048 + qblocks - 1) / qblocks;
+    c = std::min<uint32_t>(c, std::max<uint32_t>(1, n / 4096));
+    return std::max<uint32_t>(1, std::min<uint32_t>(c, 64));
+}
+size_t knn_mfma_scratch_words(uint32_t n, uint32_t nq) { return 2 * (size_t)n + (size_t)nq * knn_mfma_chunks(n, nq) * KNN_KP; }
+
+// scratch: knn_mfma_scratch_words() dwords = [scale n][bias n][candidate slots]
+void launch_exact_knn_mfma(const GraphView& g, const float* queries, uint32_t nq, uint32_t top_k, vdb_scored_point* out, uint32_t* out_n,
+                           uint32_t* scratch, hipStream_t st) {
+    if (nq == 0) return;
+    const uint32_t n_chunks = knn_mfma_chunks(g.n, nq);
+    float* scale = reinterpret_cast<float*>(scratch); float* bias = scale + g.n;
+    uint32_t* slots = scratch + 2 * (size_t)g.n;
+    hipLaunchKernelGGL(knn_prepare_kernel, dim3((g.n + 255) / 256), dim3(256), 0, st, g, scale, bias);
+    VDB_HIP(hipGetLastError());
+    if (g.stride <= 64) launch_mfma<32>(g, queries, nq, scale, bias, slots, n_chunks, st);
+    else if (g.stride <= 128) launch_mfma<64>(g, queries, nq, scale, bias, slots, n_chunks, st);
+    else launch_mfma<128>(g, queries, nq, scale, bias, slots, n_chunks, st);
+    VDB_HIP(hipGetLastError());
+    const size_t lds = (size_t)g.stride * 4 + (size_t)top_k * 16;
+    hipLaunchKernelGGL(knn_rerank_kernel, dim3(nq), dim3(64), lds, st, g, queries, top_k, slots, n_chunks * KNN_KP, out, out_n);
+    VDB_HIP(hipGetLastError());
+}
+
+}  // namespace vdb
