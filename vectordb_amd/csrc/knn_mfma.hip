@@ -15,17 +15,24 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int MQ = 128;            // queries per block: 4 waves x 32 (the N side of the 32x32 tile)
 constexpr int MT = 32;             // base rows per tile (the M side)
-constexpr int KNN_KP = 24;         // candidates kept per (query, chunk)
-constexpr int KNN_CAP = 56;        // per-query buffer: KNN_KP kept + room for one tile of pushes (32)
+constexpr int KNN_KP = 16;         // candidates kept per (query, chunk)
+constexpr int KNN_CAP = 60;        // per-query buffer; compacted to KNN_KP once fewer than 32 entries (one tile of pushes) are free
+constexpr int KNN_TRIG = KNN_CAP - 32;
 constexpr float INF_F = __builtin_inff();
 
 // scale / bias turn a dot product into the ranking key: key = dot * scale[row] + bias[row].
 __global__ void __launch_bounds__(256) knn_prepare_kernel(GraphView gv, float* __restrict__ scale, float* __restrict__ bias) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= gv.n) return;
-    const float* row = gv.vecs + (size_t)r * gv.stride;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = t >> 3, part = t & 7;                   // eight lanes share a row, 16 bytes each per step
+    const bool in = r < gv.n;
+    const float4* row = reinterpret_cast<const float4*>(gv.vecs + (size_t)(in ? r : 0) * gv.stride);
     float s = 0.f;
-    for (uint32_t d = 0; d < gv.dim; ++d) s = __builtin_fmaf(row[d], row[d], s);
+    for (uint32_t c = part; c < (gv.stride >> 2); c += 8) {
+        const float4 v = row[c];
+        s = __builtin_fmaf(v.x, v.x, s); s = __builtin_fmaf(v.y, v.y, s); s = __builtin_fmaf(v.z, v.z, s); s = __builtin_fmaf(v.w, v.w, s);
+    }
+    s = group_sum<8>(s);
+    if (!in || part != 0) return;
     float sc, bi = 0.f;
     if (gv.metric == VDB_EUCLIDEAN) { sc = -2.f; bi = s; }
     else if (gv.metric == VDB_DOT) sc = -1.f;
@@ -119,9 +126,12 @@ __global__ void __launch_bounds__(256) knn_mfma_kernel(GraphView gv, const float
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[v] = 0.f;
         const float* arow = At + j * LDA + h * KH;
+        float4 afrag[KH / 4];                     // the lane's whole slice of the tile: reads run ahead of the MFMAs
+#pragma unroll
+        for (int c = 0; c < KH / 4; ++c) afrag[c] = *reinterpret_cast<const float4*>(arow + 4 * c);
 #pragma unroll
         for (int c = 0; c < KH / 4; ++c) {
-            const float4 a4 = *reinterpret_cast<const float4*>(arow + 4 * c);
+            const float4 a4 = afrag[c];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b[4 * c + 0], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b[4 * c + 1], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b[4 * c + 2], acc, 0, 0, 0);
@@ -154,7 +164,7 @@ __global__ void __launch_bounds__(256) knn_mfma_kernel(GraphView gv, const float
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             // queries of this wave whose buffer could not take another tile
-            uint64_t need = __ballot(lane < 32 && cnt[wave * 32 + (lane & 31)] > KNN_KP);
+            uint64_t need = __ballot(lane < 32 && cnt[wave * 32 + (lane & 31)] > KNN_TRIG);
             while (need) {
                 const int jj = __ffsll((unsigned long long)need) - 1; need &= need - 1;
                 const float nt = compact(wave * 32 + jj);
@@ -255,7 +265,7 @@ void launch_mfma(const GraphView& g, const float* queries, uint32_t nq, const fl
 
 }  // namespace
 
-bool knn_mfma_supported(const GraphView& g, uint32_t top_k) { return top_k >= 1 && top_k <= 16 && g.stride <= 256 && g.n > 0; }
+bool knn_mfma_supported(const GraphView& g, uint32_t top_k) { return top_k >= 1 && top_k + 4 <= KNN_KP && g.stride <= 256 && g.n > 0; }
 uint32_t knn_mfma_chunks(uint32_t n, uint32_t nq) {
     // enough blocks to fill 256 CUs several times over, chunks of at least 4096 rows
     const uint32_t qblocks = (nq + MQ - 1) / MQ;
@@ -272,7 +282,7 @@ void launch_exact_knn_mfma(const GraphView& g, const float* queries, uint32_t nq
     const uint32_t n_chunks = knn_mfma_chunks(g.n, nq);
     float* scale = reinterpret_cast<float*>(scratch); float* bias = scale + g.n;
     uint32_t* slots = scratch + 2 * (size_t)g.n;
-    hipLaunchKernelGGL(knn_prepare_kernel, dim3((g.n + 255) / 256), dim3(256), 0, st, g, scale, bias);
+    hipLaunchKernelGGL(knn_prepare_kernel, dim3((g.n + 31) / 32), dim3(256), 0, st, g, scale, bias);
     VDB_HIP(hipGetLastError());
     if (g.stride <= 64) launch_mfma<32>(g, queries, nq, scale, bias, slots, n_chunks, st);
     else if (g.stride <= 128) launch_mfma<64>(g, queries, nq, scale, bias, slots, n_chunks, st);
