@@ -168,20 +168,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    n_streams = max(1, args.streams) if world == 1 else 1
+    n_streams = max(1, args.streams)
     lanes = [(stream, d_out, d_n, d_stats)]
     for _ in range(n_streams - 1):
         lanes.append((torch.cuda.Stream(device=dev), torch.zeros_like(d_out), torch.zeros_like(d_n), torch.zeros_like(d_stats)))
+    searched = [torch.cuda.Event() for _ in lanes]      # search of the lane's current step is enqueued
+    merged_ev = [None for _ in lanes]                   # the exchange that last read the lane's buffers
 
     def launch(lane):
         st_, o_, n_, s_ = lane
         vdb.check(vdb.fn.index_search_batch_dev(index._h, d_q.data_ptr(), Q, K, ef, o_.data_ptr(), n_.data_ptr(), s_.data_ptr(), st_.cuda_stream))
 
     def one_step(i):
-        launch(lanes[i % n_streams])
+        li = i % n_streams
+        lane = lanes[li]
+        if world > 1 and merged_ev[li] is not None:
+            lane[0].wait_event(merged_ev[li])           # the previous exchange has consumed these buffers
+        launch(lane)
         if world > 1:
-            stream.synchronize()
-            merged(d_out, d_n)
+            # exchange + merge on torch's current stream, ordered after this lane's search by an
+            # event (no host synchronisation): the next step's search overlaps it on the other lane
+            searched[li].record(lane[0])
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_event(searched[li])
+            merged(lane[1], lane[2])
+            merged_ev[li] = torch.cuda.Event(); merged_ev[li].record(cur)
 
     # (A) back to back on ONE stream, HIP events on that stream: the kernel's own average duration
     for i in range(args.warmup):
