@@ -554,11 +554,21 @@ struct Searcher {
                 if (full) score_rows<true>(m); else score_rows<false>(m);
                 VDB_T_MARK(3);
                 // ---- merge cand[0..m) / craw[0..m), 64 candidates per round, lane j <-> candidate j ----
+                // (all candidates are read into registers first: the permutation reuses their LDS area)
+                float kjr[CAND_CAP / WAVE]; uint32_t sjr[CAND_CAP / WAVE];
+#pragma unroll
+                for (int r = 0; r < CAND_CAP / WAVE; ++r) {
+                    const int j = r * WAVE + lane;
+                    kjr[r] = j < m ? key_of(craw[j]) : INF;
+                    sjr[r] = j < m ? cand[j] : 0u;
+                }
+                wave_sync();
                 for (int base = 0; base < m; base += WAVE) {
                     const int j = base + lane;
                     const bool have = j < m;
-                    float kj = have ? key_of(craw[j]) : INF;
-                    const uint32_t sj = have ? cand[j] : 0u;
+                    float kj = kjr[0]; uint32_t sj = sjr[0];
+#pragma unroll
+                    for (int r = 1; r < CAND_CAP / WAVE; ++r) if (base == r * WAVE) { kj = kjr[r]; sj = sjr[r]; }
                     const bool pass = have && (n < cap || kj < worst);            // hnsw.rs:486
                     const uint64_t pm = ballot(pass);
                     if (pm == 0) continue;
@@ -715,14 +725,17 @@ struct Searcher {
         if (NC > 0 && MODE == MODE_SEARCH) {
             // register-resident list: LDS only stages permutations, the query (until it is in
             // registers) and the final list, all in one area
-            const size_t area = (size_t)NCC * WAVE * 8 > (size_t)gv.stride * 4 ? (size_t)NCC * WAVE * 8 : (size_t)gv.stride * 4;
+            // (candidate ids + scores, then the permutation of the merge, which has read them into registers)
+            size_t area = (size_t)CAND_CAP * 8;
+            if ((size_t)NCC * WAVE * 8 > area) area = (size_t)NCC * WAVE * 8;
+            if ((size_t)gv.stride * 4 > area) area = (size_t)gv.stride * 4;
             perm = reinterpret_cast<uint2*>(smem);
             qlds = reinterpret_cast<float*>(smem);
             R.key = reinterpret_cast<float*>(smem); R.val = reinterpret_cast<uint32_t*>(smem) + NCC * WAVE;
             R.key2 = nullptr; R.val2 = nullptr;
+            cand = reinterpret_cast<uint32_t*>(smem);
+            craw = reinterpret_cast<float*>(smem + CAND_CAP * 4);
             off = (area + 15) & ~(size_t)15;
-            cand = reinterpret_cast<uint32_t*>(smem + off); off += CAND_CAP * 4;
-            craw = reinterpret_cast<float*>(smem + off); off += CAND_CAP * 4;
             tags.tab = reinterpret_cast<uint32_t*>(smem + off); off += (size_t)2 << a.tag_log2;
             tags.sec = reinterpret_cast<uint32_t*>(smem + off); off += SEC_IDS * 4;
         } else {
