@@ -205,6 +205,38 @@ def test_exact_knn_matrix_core_pass_matches_brute_force(ora, vdb, metric, dim):
         assert np.array_equal(ref["sort_key"].view(np.uint32), got["sort_key"].view(np.uint32))
 
 
+@pytest.mark.parametrize("name,metric,n,dim,nq,ef", [
+    ("C1", 0, 10000, 128, 1000, 64),          # 10k x 128 cosine, uniform(-1, 1), M=16, ef=64
+    ("C3-reduced", 0, 6000, 960, 200, 64),    # 960-d cosine rows (3840 B), clustered
+    ("wide-rows", 2, 4000, 200, 200, 100),    # 200-d L2: one row per wavefront pass
+])
+def test_reference_configurations(ora, vdb, name, metric, n, dim, nq, ef):
+    """The smaller benchmark configurations as parity cases: STRICT search bit-identical to the oracle on the
+    oracle-built graph, FAST (one node per step) ids equal outside near-ties, FAST default recall within 0.5 pt."""
+    k = 10
+    kind = "uniform" if name == "C1" else "clustered"
+    h, x = build_oracle(ora, metric, n, dim, seed=0xC1, kind=kind)
+    g = h.export_graph()
+    q = data(nq, dim, 0xC1 + 1, kind)
+    ref, refn, rst = h.search_batch(q, k, ef_search=ef, with_stats=True)
+    exact, exact_n = h.exact_knn_batch(q, k)
+    ps = vdb.HNSWIndex(metric, 16, 64, 16, dim, arith=vdb.Arith.Strict); ps.import_graph(g)
+    got, gotn, st = ps.search_batch(q, k, ef_search=ef, with_stats=True)
+    compare_results(ref, refn, got, gotn, exact=True)
+    assert np.array_equal(rst["expanded"], st["expanded"])
+    e2, e2n = ps.exact_knn_batch(q, k)
+    assert np.array_equal(exact["id"], e2["id"]) and np.array_equal(exact["raw_score"].view(np.uint32), e2["raw_score"].view(np.uint32))
+    p1 = vdb.HNSWIndex(metric, 16, 64, 16, dim, arith=vdb.Arith.Fast, beam_width=1); p1.import_graph(g)
+    got, gotn = p1.search_batch(q, k, ef_search=ef)
+    assert compare_results(ref, refn, got, gotn, exact=False) <= nq * k // 200
+    pw = vdb.HNSWIndex(metric, 16, 64, 16, dim, arith=vdb.Arith.Fast); pw.import_graph(g)
+    got, gotn, st = pw.search_batch(q, k, ef_search=ef, with_stats=True)
+    assert not (st["flags"] & 1).any()
+    assert _recall(got, gotn, exact, exact_n, k) >= _recall(ref, refn, exact, exact_n, k) - 0.005
+    e3, e3n = pw.exact_knn_batch(q, k)
+    assert np.array_equal(exact["id"], e3["id"]) and np.array_equal(exact["raw_score"].view(np.uint32), e3["raw_score"].view(np.uint32))
+
+
 def test_exact_knn_ties_break_by_id(ora, vdb):
     d = 8
     base = np.zeros((40, d), np.float32); base[:, 0] = np.repeat(np.arange(10), 4)     # 4-way exact ties
