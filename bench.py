@@ -76,7 +76,9 @@ def main():
     import torch                                   # before libvdbmi: one HIP runtime per process
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # VDB_BENCH_EXCHANGE=1 under torchrun with one rank rehearses the multi-GPU step (all-gather + merge) on one GPU
+    exchange = world > 1 or (os.environ.get("VDB_BENCH_EXCHANGE") == "1" and "RANK" in os.environ)
+    if exchange:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
     import vectordb_amd
@@ -121,7 +123,7 @@ def main():
         return out, d_n.cpu().numpy().view(np.uint32), d_stats.cpu().numpy().view(vdb.STATS_DTYPE).reshape(Q)
 
     from vectordb_amd.sharded import ShardedIndex
-    shards = ShardedIndex(vdb, index, device=dev)
+    shards = ShardedIndex(vdb, index, device=dev, always_exchange=exchange)
 
     def merged(out_t, n_t):
         """all-gather per-shard lists and merge them on the GPU (one exchange step)."""
@@ -164,7 +166,7 @@ def main():
 
     # ---- timed regions ----
     def barrier():
-        if world > 1:
+        if exchange:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -182,10 +184,10 @@ def main():
     def one_step(i):
         li = i % n_streams
         lane = lanes[li]
-        if world > 1 and merged_ev[li] is not None:
+        if exchange and merged_ev[li] is not None:
             lane[0].wait_event(merged_ev[li])           # the previous exchange has consumed these buffers
         launch(lane)
-        if world > 1:
+        if exchange:
             # exchange + merge on torch's current stream, ordered after this lane's search by an
             # event (no host synchronisation): the next step's search overlaps it on the other lane
             searched[li].record(lane[0])
@@ -215,7 +217,7 @@ def main():
         one_step(i)
     barrier()
     wall = time.perf_counter() - t0
-    if world > 1:
+    if exchange:
         tt = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
@@ -285,7 +287,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if exchange:
         dist.destroy_process_group()
 
 

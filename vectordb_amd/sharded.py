@@ -39,8 +39,9 @@ class ShardedIndex:
     `api.HNSWIndex`.  `world == 1` (or no process group) makes every call a plain local search.
     """
 
-    def __init__(self, api, index, group=None, device=None):
+    def __init__(self, api, index, group=None, device=None, always_exchange=False):
         self.api, self.index, self.group, self.device = api, index, group, device
+        self.always_exchange = always_exchange      # run the exchange step even in a world of one (rehearsal)
         self.rank, self.world = 0, 1
         if group is not None or _dist_ready():
             import torch.distributed as dist
@@ -87,7 +88,7 @@ class ShardedIndex:
         """d_out: uint8 tensor of nq*k*16 B (or world x that when `gathered`), d_cnt: int32 tensor of nq
         (world x nq).  Runs on torch's current stream of the tensors' device; returns device tensors."""
         import torch
-        if self.world == 1 and not gathered:
+        if self.world == 1 and not gathered and not self.always_exchange:
             return d_out, d_cnt
         if not gathered:
             import torch.distributed as dist
