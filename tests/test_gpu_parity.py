@@ -237,6 +237,63 @@ def test_reference_configurations(ora, vdb, name, metric, n, dim, nq, ef):
     assert np.array_equal(exact["id"], e3["id"]) and np.array_equal(exact["raw_score"].view(np.uint32), e3["raw_score"].view(np.uint32))
 
 
+def test_high_degree_nodes_deleted_rows_and_long_lists(ora, vdb):
+    """Register-resident beam off the beaten path: nodes with more than 62 neighbours (overflow chunks of the
+    adjacency block), tombstones inside the wide step, ef > 256 (LDS list) — all against the oracle."""
+    metric, n, d, nq, k = 2, 5000, 16, 200, 10
+    rng = np.random.default_rng(3)
+    x = rng.normal(0, 1, size=(n, d)).astype(np.float32)
+    x[:40] *= 0.05                                           # a tight core: every later point links to it
+    h = ora.HNSWIndex(metric, 16, 64, 16, d, seed=9)
+    for i in range(n):
+        h.insert(i * 3 + 1, x[i])
+    g = h.export_graph()
+    ow, of, nb = g["layers"][0]
+    assert (np.diff(of.astype(np.int64)) > 62).sum() >= 5, "the data set is meant to produce high-degree nodes"
+    q = rng.normal(0, 1, size=(nq, d)).astype(np.float32)
+    kill = [int(v) for v in rng.choice(g["ids"], size=600, replace=False)]
+    ps = vdb.HNSWIndex(metric, 16, 64, 16, d, arith=vdb.Arith.Strict); ps.import_graph(g)
+    p1 = vdb.HNSWIndex(metric, 16, 64, 16, d, beam_width=1); p1.import_graph(g)
+    pw = vdb.HNSWIndex(metric, 16, 64, 16, d); pw.import_graph(g)
+    for phase in ("fresh", "deleted"):
+        if phase == "deleted":
+            for pid in kill:
+                h.mark_deleted(pid); ps.mark_deleted(pid); p1.mark_deleted(pid); pw.mark_deleted(pid)
+        exact, exact_n = h.exact_knn_batch(q, k)
+        for ef in (64, 200, 400):
+            ref, refn = h.search_batch(q, k, ef_search=ef)
+            got, gotn = ps.search_batch(q, k, ef_search=ef)
+            compare_results(ref, refn, got, gotn, exact=True)
+            got, gotn = p1.search_batch(q, k, ef_search=ef)
+            assert compare_results(ref, refn, got, gotn, exact=False) <= nq * k // 200
+            got, gotn = pw.search_batch(q, k, ef_search=ef)
+            assert np.array_equal(refn, gotn)
+            assert _recall(got, gotn, exact, exact_n, k) >= _recall(ref, refn, exact, exact_n, k) - 0.005
+            if phase == "deleted":
+                assert not (set(got["id"].ravel().tolist()) & set(kill))
+
+
+def test_visited_table_overflow_is_finished_by_the_follow_up_launch(ora, vdb, monkeypatch):
+    """A visited set that outgrows the LDS tag table: the query is flagged, re-run by the follow-up launch of the
+    LDS-list kernel, and the caller sees complete results (no overflow flag left)."""
+    metric, n, d, nq, k = 2, 20000, 32, 300, 10
+    h, x = build_oracle(ora, metric, n, d, seed=44, kind="clustered")
+    g = h.export_graph()
+    q = data(nq, d, 45, "clustered")
+    exact, exact_n = h.exact_knn_batch(q, k)
+    ref, refn = h.search_batch(q, k, ef_search=256)
+    monkeypatch.setenv("VDB_TAG_LOG2", "11")                 # 2048 tags: the walk of ef = 256 does not fit
+    p = vdb.HNSWIndex(metric, 16, 64, 16, d); p.import_graph(g)
+    got, gotn, st = p.search_batch(q, k, ef_search=256, with_stats=True)
+    monkeypatch.delenv("VDB_TAG_LOG2")
+    big, bign, st_big = p.search_batch(q, k, ef_search=256, with_stats=True)
+    assert not (st["flags"] & 1).any() and not (st_big["flags"] & 1).any()
+    assert np.array_equal(refn, gotn)
+    assert (st["rows_scored"] > 1300).sum() > 0, "the case is meant to overflow the small table"
+    assert _recall(got, gotn, exact, exact_n, k) >= _recall(ref, refn, exact, exact_n, k) - 0.005
+    assert _recall(big, bign, exact, exact_n, k) >= _recall(ref, refn, exact, exact_n, k) - 0.005
+
+
 def test_exact_knn_ties_break_by_id(ora, vdb):
     d = 8
     base = np.zeros((40, d), np.float32); base[:, 0] = np.repeat(np.arange(10), 4)     # 4-way exact ties

@@ -228,7 +228,7 @@ uint32_t vdb_index::pick_hash_log2(size_t, bool& global) const {
     // 4096 ids (16 KiB of LDS) keep eight search wavefronts resident per CU; a query that visits
     // more rows than that continues in a spill table in HBM (see Visited in kernels.hip)
     global = false;
-    static const int forced = [] { const char* e = getenv("VDB_HASH_LOG2"); return e ? atoi(e) : 0; }();
+    const char* fe = getenv("VDB_HASH_LOG2"); const int forced = fe ? atoi(fe) : 0;
     return (forced >= 10 && forced <= 14) ? (uint32_t)forced : 12;
 }
 
@@ -238,7 +238,7 @@ uint32_t vdb_index::pick_hash_log2(size_t, bool& global) const {
 void vdb_index::run_search(SearchArgs a, size_t nq, hipStream_t s, bool retry_on_overflow, const float* d_q_all) {
     bool global = false;
     a.hash_log2 = pick_hash_log2(a.ef, global);
-    static const int forced_tags = [] { const char* e = getenv("VDB_TAG_LOG2"); return e ? atoi(e) : 0; }();
+    const char* te = getenv("VDB_TAG_LOG2"); const int forced_tags = te ? atoi(te) : 0;
     a.tag_log2 = (forced_tags >= 11 && forced_tags <= 15) ? (uint32_t)forced_tags : 13;
     // one spill table per possibly resident wavefront (256 CUs x 16), 2^15 ids each
     a.spill_log2 = 15;
