@@ -170,10 +170,25 @@ struct Searcher {
                 if (!have_cur && !with_cur) { kcur = key_of(score_one(cur)); have_cur = true; if (ok) cand[rnk] = nb; }
                 if (with_cur && lane == 0) cand[m] = cur;
                 wave_sync();
-                score(with_cur ? m + 1 : m);
+                int scored = m;
+                if (STRICT || with_cur) score(with_cur ? m + 1 : m);
+                else {
+                    // in list order, one batch of rows at a time: the first batch that holds an improving
+                    // neighbour decides the move, the rest of the list is never fetched
+                    scored = 0;
+                    while (scored < m) {
+                        const int cnt = (m - scored) < BATCH ? (m - scored) : BATCH;
+                        score_cands_fast<GG, CC, PP, METRIC>(gv, qr, cand + scored, cnt, craw + scored);
+                        wave_sync();
+                        rows_scored += cnt;
+                        const bool mine = lane >= scored && lane < scored + cnt;
+                        scored += cnt;
+                        if (ballot(mine && key_of(craw[lane]) < kcur)) break;
+                    }
+                }
                 if (with_cur) { kcur = key_of(craw[m]); have_cur = true; }
-                const float kl = lane < m ? key_of(craw[lane]) : 0.f;
-                const uint64_t bm = ballot(lane < m && kl < kcur);
+                const float kl = lane < scored ? key_of(craw[lane]) : 0.f;
+                const uint64_t bm = ballot(lane < scored && kl < kcur);
                 if (bm) {
                     const int j = __ffsll((unsigned long long)bm) - 1;
                     const uint64_t src = ballot(ok && rnk == (uint32_t)j);       // the lane that holds candidate j
