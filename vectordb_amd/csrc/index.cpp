@@ -48,6 +48,10 @@ std::vector<uint32_t>& vdb_index::list_or_default(size_t level, uint32_t slot) {
     if (L.idx.size() <= slot) L.idx.resize(std::max<size_t>(slot + 1, ids.size()), -1);
     if (L.idx[slot] < 0) { L.idx[slot] = (int32_t)L.lists.size(); L.lists.emplace_back(); L.owner.push_back(slot); }
     graph_dirty = true;
+    if (level == 0) {                       // the device copy of layer 0 is patched list by list
+        if (dirty0_mark.size() <= slot) dirty0_mark.resize(std::max<size_t>(slot + 1, ids.size()), 0);
+        if (!dirty0_mark[slot]) { dirty0_mark[slot] = 1; dirty0.push_back(slot); }
+    } else upper_dirty = true;
     return L.lists[L.idx[slot]];
 }
 
@@ -119,82 +123,150 @@ std::vector<float> vdb_index::maybe_normalize(const float* v) {     // hnsw.rs:7
 // ------------------------------------------------------------------------------------------------
 // Device copy of the graph: rows are already resident; lists are packed with self loops and
 // duplicate ids removed (the visited set makes both invisible to every search, hnsw.rs:475).
+void vdb_index::clean_list(const std::vector<uint32_t>& src, uint32_t self, std::vector<uint32_t>& out) {
+    // drop self loops and repeats, keep order
+    if (clean_stamp.size() < ids.size()) clean_stamp.resize(ids.size(), 0);
+    if (++clean_epoch == 0) { std::fill(clean_stamp.begin(), clean_stamp.end(), 0); clean_epoch = 1; }
+    out.clear();
+    for (uint32_t x : src) { if (x == self || clean_stamp[x] == clean_epoch) continue; clean_stamp[x] = clean_epoch; out.push_back(x); }
+}
+
+// One layer-0 list as its device block; neighbours beyond the 62nd go to the end of `ovf`.
+void vdb_index::fill_block(uint32_t* blk, const std::vector<uint32_t>& lst, std::vector<uint32_t>& ovf, size_t ovf_base) {
+    std::fill(blk, blk + ADJ_BLOCK, 0u);
+    blk[0] = (uint32_t)lst.size();
+    const size_t inl = std::min<size_t>(lst.size(), ADJ_INLINE);
+    std::copy(lst.begin(), lst.begin() + inl, blk + 1);
+    if (lst.size() > ADJ_INLINE) { blk[63] = (uint32_t)(ovf_base + ovf.size()); ovf.insert(ovf.end(), lst.begin() + ADJ_INLINE, lst.end()); }
+}
+
+// Layer 0 from scratch.
+void vdb_index::pack_layer0_full() {
+    const size_t n = ids.size();
+    std::vector<uint32_t> adj0(n * ADJ_BLOCK, 0), ovf, tmp;
+    h_deg0.assign(n, 0);
+    size_t edges = 0;
+    if (!layers.empty()) {
+        const HostLayer& L0 = layers[0];
+        for (size_t k = 0; k < L0.lists.size(); ++k) {
+            const uint32_t s = L0.owner[k];
+            clean_list(L0.lists[k], s, tmp);
+            fill_block(&adj0[(size_t)s * ADJ_BLOCK], tmp, ovf, 0);
+            h_deg0[s] = (uint32_t)tmp.size(); edges += tmp.size();
+        }
+    }
+    l0_edges = edges; ovf_used = ovf.size();
+    const size_t n1 = std::max<size_t>(n, 1);
+    d_adj0.reserve(n1 * ADJ_BLOCK, stream, false); d_ovf.reserve(std::max<size_t>(ovf.size(), 1), stream, false);
+    if (n) VDB_HIP(hipMemcpyAsync(d_adj0.p, adj0.data(), adj0.size() * 4, hipMemcpyHostToDevice, stream));
+    if (!ovf.empty()) VDB_HIP(hipMemcpyAsync(d_ovf.p, ovf.data(), ovf.size() * 4, hipMemcpyHostToDevice, stream));
+    VDB_HIP(hipStreamSynchronize(stream));
+}
+
+// Layer 0 after a few edits: only the blocks of the lists that changed are rebuilt and written over
+// the device copy; a list that outgrows its block gets a fresh overflow run at the end of `ovf` (the
+// old run is garbage until the next full pack).
+void vdb_index::patch_layer0() {
+    const size_t n = ids.size();
+    d_adj0.reserve(std::max<size_t>(n, 1) * ADJ_BLOCK, stream, true);
+    h_deg0.resize(n, 0);
+    std::vector<uint32_t> idx, blocks(dirty0.size() * ADJ_BLOCK), ovf, tmp;
+    idx.reserve(dirty0.size());
+    for (uint32_t s : dirty0) {
+        const std::vector<uint32_t>* lst = list(0, s);
+        if (lst) clean_list(*lst, s, tmp); else tmp.clear();
+        fill_block(&blocks[idx.size() * ADJ_BLOCK], tmp, ovf, ovf_used);
+        l0_edges += tmp.size(); l0_edges -= h_deg0[s]; h_deg0[s] = (uint32_t)tmp.size();
+        idx.push_back(s);
+    }
+    if (!ovf.empty()) {
+        d_ovf.reserve(ovf_used + ovf.size(), stream, true);
+        VDB_HIP(hipMemcpyAsync(d_ovf.p + ovf_used, ovf.data(), ovf.size() * 4, hipMemcpyHostToDevice, stream));
+        ovf_used += ovf.size();
+    }
+    if (!idx.empty()) {
+        s_patch_idx.reserve(idx.size(), stream, false); s_patch_blk.reserve(blocks.size(), stream, false);
+        VDB_HIP(hipMemcpyAsync(s_patch_idx.p, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, stream));
+        VDB_HIP(hipMemcpyAsync(s_patch_blk.p, blocks.data(), blocks.size() * 4, hipMemcpyHostToDevice, stream));
+        launch_patch_blocks(d_adj0.p, s_patch_idx.p, s_patch_blk.p, (uint32_t)idx.size(), stream);
+    }
+    VDB_HIP(hipStreamSynchronize(stream));
+}
+
+// Upper layers from scratch (they hold about 1/M of the points): descriptor lists for the LDS-list
+// kernels and the fused blocks of the greedy descent.
+void vdb_index::pack_upper() {
+    const size_t n = ids.size();
+    std::vector<uint32_t> pool, upper_base(n, NONE32), tmp;
+    std::vector<uint64_t> udesc;
+    std::vector<uint8_t> upper_cnt(n, 0);
+    // a slot's descriptors for layers 1..cnt are consecutive in udesc
+    for (size_t l = 1; l < layers.size(); ++l)
+        for (uint32_t s : layers[l].owner) upper_cnt[s] = std::max<uint8_t>(upper_cnt[s], (uint8_t)std::min<size_t>(l, 255));
+    for (uint32_t s = 0; s < n; ++s) {
+        if (!upper_cnt[s]) continue;
+        upper_base[s] = (uint32_t)udesc.size();
+        for (size_t l = 1; l <= upper_cnt[s]; ++l) {
+            const std::vector<uint32_t>* lst = list(l, s);
+            if (!lst) { udesc.push_back(make_desc(0, 0)); continue; }
+            clean_list(*lst, s, tmp);
+            udesc.push_back(make_desc(pool.size(), (uint32_t)tmp.size()));
+            pool.insert(pool.end(), tmp.begin(), tmp.end());
+        }
+    }
+    // fused upper-layer blocks (see GraphView::ublk); skipped when the packed reference cannot hold the counts
+    std::vector<uint32_t> ublk, ublk_ref;
+    have_ublk = udesc.size() < (size_t(1) << UREF_BITS) && pool.size() < (size_t(1) << 32);
+    for (uint32_t s = 0; s < n && have_ublk; ++s) if (upper_cnt[s] > 63) have_ublk = false;
+    if (have_ublk) {
+        ublk.assign(udesc.size() * ADJ_BLOCK, 0); ublk_ref.assign(udesc.size() * ADJ_BLOCK, 0);
+        for (size_t d = 0; d < udesc.size(); ++d) {
+            const uint64_t off = udesc[d] & 0xFFFFFFFFFFull; const uint32_t deg = (uint32_t)(udesc[d] >> 40);
+            uint32_t* blk = &ublk[d * ADJ_BLOCK]; uint32_t* ref = &ublk_ref[d * ADJ_BLOCK];
+            blk[0] = deg; blk[63] = (uint32_t)(off + ADJ_INLINE);
+            for (uint32_t i = 0; i < std::min<uint32_t>(deg, ADJ_INLINE); ++i) {
+                const uint32_t nb = pool[off + i];
+                blk[1 + i] = nb; ref[1 + i] = make_uref(upper_base[nb], upper_cnt[nb]);
+            }
+        }
+    }
+    upper_edges = pool.size(); upper_words = udesc.size() * 2 + pool.size() + (have_ublk ? ublk.size() * 2 : 0);
+    const size_t n1 = std::max<size_t>(n, 1);
+    d_upper_base.reserve(n1, stream, false); d_upper_cnt.reserve(n1, stream, false);
+    d_udesc.reserve(std::max<size_t>(udesc.size(), 1), stream, false); d_pool.reserve(std::max<size_t>(pool.size(), 1), stream, false);
+    if (n) {
+        VDB_HIP(hipMemcpyAsync(d_upper_base.p, upper_base.data(), n * 4, hipMemcpyHostToDevice, stream));
+        VDB_HIP(hipMemcpyAsync(d_upper_cnt.p, upper_cnt.data(), n, hipMemcpyHostToDevice, stream));
+    }
+    if (!udesc.empty()) VDB_HIP(hipMemcpyAsync(d_udesc.p, udesc.data(), udesc.size() * 8, hipMemcpyHostToDevice, stream));
+    if (!pool.empty()) VDB_HIP(hipMemcpyAsync(d_pool.p, pool.data(), pool.size() * 4, hipMemcpyHostToDevice, stream));
+    if (have_ublk && !ublk.empty()) {
+        d_ublk.reserve(ublk.size(), stream, false); d_ublk_ref.reserve(ublk_ref.size(), stream, false);
+        VDB_HIP(hipMemcpyAsync(d_ublk.p, ublk.data(), ublk.size() * 4, hipMemcpyHostToDevice, stream));
+        VDB_HIP(hipMemcpyAsync(d_ublk_ref.p, ublk_ref.data(), ublk_ref.size() * 4, hipMemcpyHostToDevice, stream));
+    }
+    VDB_HIP(hipStreamSynchronize(stream));
+    upper_slots = n;
+}
+
 void vdb_index::sync_device() {
     use_device();
     const size_t n = ids.size();
     if (graph_dirty) {
-        std::vector<uint32_t> adj0(n * ADJ_BLOCK, 0), ovf, pool, upper_base(n, NONE32);
-        std::vector<uint64_t> udesc;
-        std::vector<uint8_t> upper_cnt(n, 0);
-        std::vector<uint32_t> stamp(n, 0), tmp; uint32_t epoch = 0;
-        auto clean = [&](const std::vector<uint32_t>& src, uint32_t self) {    // drop self loops and repeats, keep order
-            ++epoch; tmp.clear();
-            for (uint32_t x : src) { if (x == self || stamp[x] == epoch) continue; stamp[x] = epoch; tmp.push_back(x); }
-        };
-        if (!layers.empty()) {
-            const HostLayer& L0 = layers[0];
-            for (size_t k = 0; k < L0.lists.size(); ++k) {
-                const uint32_t s = L0.owner[k];
-                clean(L0.lists[k], s);
-                uint32_t* blk = &adj0[(size_t)s * ADJ_BLOCK];
-                blk[0] = (uint32_t)tmp.size();
-                const size_t inl = std::min<size_t>(tmp.size(), ADJ_INLINE);
-                std::copy(tmp.begin(), tmp.begin() + inl, blk + 1);
-                if (tmp.size() > ADJ_INLINE) { blk[63] = (uint32_t)ovf.size(); ovf.insert(ovf.end(), tmp.begin() + ADJ_INLINE, tmp.end()); }
-                l0_edges_acc += tmp.size();
-            }
+        const bool full = need_full || d_adj0.cap == 0 || dirty0.size() * 8 > n;
+        if (full) pack_layer0_full(); else patch_layer0();
+        if (full || upper_dirty) pack_upper();
+        else if (upper_slots != n) {             // new points without upper lists: default entries only
+            d_upper_base.reserve(n, stream, true); d_upper_cnt.reserve(n, stream, true);
+            std::vector<uint32_t> nb(n - upper_slots, NONE32);
+            VDB_HIP(hipMemcpyAsync(d_upper_base.p + upper_slots, nb.data(), nb.size() * 4, hipMemcpyHostToDevice, stream));
+            VDB_HIP(hipMemsetAsync(d_upper_cnt.p + upper_slots, 0, n - upper_slots, stream));
+            VDB_HIP(hipStreamSynchronize(stream));
+            upper_slots = n;
         }
-        // upper layers: a slot's descriptors for layers 1..cnt are consecutive in udesc
-        for (size_t l = 1; l < layers.size(); ++l)
-            for (uint32_t s : layers[l].owner) upper_cnt[s] = std::max<uint8_t>(upper_cnt[s], (uint8_t)std::min<size_t>(l, 255));
-        for (uint32_t s = 0; s < n; ++s) {
-            if (!upper_cnt[s]) continue;
-            upper_base[s] = (uint32_t)udesc.size();
-            for (size_t l = 1; l <= upper_cnt[s]; ++l) {
-                const std::vector<uint32_t>* lst = list(l, s);
-                if (!lst) { udesc.push_back(make_desc(0, 0)); continue; }
-                clean(*lst, s);
-                udesc.push_back(make_desc(pool.size(), (uint32_t)tmp.size()));
-                pool.insert(pool.end(), tmp.begin(), tmp.end());
-            }
-        }
-        // fused upper-layer blocks (see GraphView::ublk); skipped when the packed reference cannot hold the counts
-        std::vector<uint32_t> ublk, ublk_ref;
-        have_ublk = udesc.size() < (size_t(1) << UREF_BITS);
-        for (uint32_t s = 0; s < n && have_ublk; ++s) if (upper_cnt[s] > 63) have_ublk = false;
-        if (have_ublk) {
-            ublk.assign(udesc.size() * ADJ_BLOCK, 0); ublk_ref.assign(udesc.size() * ADJ_BLOCK, 0);
-            for (size_t d = 0; d < udesc.size(); ++d) {
-                const uint64_t off = udesc[d] & 0xFFFFFFFFFFull; const uint32_t deg = (uint32_t)(udesc[d] >> 40);
-                uint32_t* blk = &ublk[d * ADJ_BLOCK]; uint32_t* ref = &ublk_ref[d * ADJ_BLOCK];
-                blk[0] = deg; blk[63] = (uint32_t)(off + ADJ_INLINE);
-                for (uint32_t i = 0; i < std::min<uint32_t>(deg, ADJ_INLINE); ++i) {
-                    const uint32_t nb = pool[off + i];
-                    blk[1 + i] = nb; ref[1 + i] = make_uref(upper_base[nb], upper_cnt[nb]);
-                }
-            }
-            if (pool.size() >= (size_t(1) << 32)) have_ublk = false;
-        }
-        l0_edges = l0_edges_acc; l0_edges_acc = 0; upper_edges = pool.size();
-        const size_t n1 = std::max<size_t>(n, 1);
-        d_adj0.reserve(n1 * ADJ_BLOCK, stream, false); d_ovf.reserve(std::max<size_t>(ovf.size(), 1), stream, false);
-        d_upper_base.reserve(n1, stream, false); d_upper_cnt.reserve(n1, stream, false);
-        d_udesc.reserve(std::max<size_t>(udesc.size(), 1), stream, false); d_pool.reserve(std::max<size_t>(pool.size(), 1), stream, false);
-        if (n) {
-            VDB_HIP(hipMemcpyAsync(d_adj0.p, adj0.data(), adj0.size() * 4, hipMemcpyHostToDevice, stream));
-            VDB_HIP(hipMemcpyAsync(d_upper_base.p, upper_base.data(), n * 4, hipMemcpyHostToDevice, stream));
-            VDB_HIP(hipMemcpyAsync(d_upper_cnt.p, upper_cnt.data(), n, hipMemcpyHostToDevice, stream));
-        }
-        if (!ovf.empty()) VDB_HIP(hipMemcpyAsync(d_ovf.p, ovf.data(), ovf.size() * 4, hipMemcpyHostToDevice, stream));
-        if (!udesc.empty()) VDB_HIP(hipMemcpyAsync(d_udesc.p, udesc.data(), udesc.size() * 8, hipMemcpyHostToDevice, stream));
-        if (!pool.empty()) VDB_HIP(hipMemcpyAsync(d_pool.p, pool.data(), pool.size() * 4, hipMemcpyHostToDevice, stream));
-        if (have_ublk && !ublk.empty()) {
-            d_ublk.reserve(ublk.size(), stream, false); d_ublk_ref.reserve(ublk_ref.size(), stream, false);
-            VDB_HIP(hipMemcpyAsync(d_ublk.p, ublk.data(), ublk.size() * 4, hipMemcpyHostToDevice, stream));
-            VDB_HIP(hipMemcpyAsync(d_ublk_ref.p, ublk_ref.data(), ublk_ref.size() * 4, hipMemcpyHostToDevice, stream));
-        }
-        VDB_HIP(hipStreamSynchronize(stream));
-        device_bytes = n * (size_t)stride * 4 + n * 8 + adj0.size() * 4 + ovf.size() * 4 + n * 5 + udesc.size() * 8 + pool.size() * 4 + (have_ublk ? ublk.size() * 8 : 0);
+        for (uint32_t s : dirty0) dirty0_mark[s] = 0;
+        dirty0.clear(); upper_dirty = false; need_full = false;
+        device_bytes = n * (size_t)stride * 4 + n * 8 + n * ADJ_BLOCK * 4 + ovf_used * 4 + n * 5 + upper_words * 4;
         graph_dirty = false;
     }
     if (deleted_dirty) {
@@ -590,6 +662,7 @@ void vdb_index::import_graph(size_t n, const uint64_t* pids, const uint32_t* lv,
                              size_t n_layers, const vdb_layer_csr* csr, bool has_entry, uint64_t entry, size_t cur_max) {
     use_device();
     ids.clear(); slot_of.clear(); levels.clear(); hvecs.clear(); layers.clear(); deleted.clear(); live.clear();
+    dirty0.clear(); dirty0_mark.clear(); need_full = true;
     n_deleted = 0; rows_on_device = 0;
     ids.assign(pids, pids + n); hvecs.assign(vecs, vecs + n * dim);
     levels.resize(n); deleted.assign(n, 0);

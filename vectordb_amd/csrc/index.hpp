@@ -66,6 +66,12 @@ struct vdb_index {
     vdb::DevBuf<uint32_t> d_adj0, d_ovf, d_upper_base, d_pool, d_deleted, d_ublk, d_ublk_ref;
     bool have_ublk = false; vdb::DevBuf<uint8_t> d_upper_cnt;
     size_t rows_on_device = 0; bool graph_dirty = true, deleted_dirty = true;
+    // incremental device copy of layer 0: lists edited since the last sync, the degree each block holds on the
+    // device, the part of `ovf` in use; upper layers are re-packed as a whole when any of their lists changed
+    std::vector<uint32_t> dirty0, h_deg0, clean_stamp; std::vector<uint8_t> dirty0_mark;
+    uint32_t clean_epoch = 0; bool upper_dirty = true, need_full = true;
+    size_t ovf_used = 0, upper_words = 0, upper_slots = 0;
+    vdb::DevBuf<uint32_t> s_patch_idx, s_patch_blk;
     size_t l0_edges = 0, upper_edges = 0, device_bytes = 0, l0_edges_acc = 0;
     // per-call scratch (guarded by mu)
     mutable std::mutex mu;
@@ -93,6 +99,9 @@ struct vdb_index {
 
     // device
     void sync_device();                                      // upload rows / packed graph / tombstones if stale
+    void pack_layer0_full(); void patch_layer0(); void pack_upper();
+    void clean_list(const std::vector<uint32_t>& src, uint32_t self, std::vector<uint32_t>& out);
+    static void fill_block(uint32_t* blk, const std::vector<uint32_t>& lst, std::vector<uint32_t>& ovf, size_t ovf_base);
     vdb::GraphView view() const;
     struct FilterArgs { int mode = vdb::MODE_SEARCH; const vdb::FilterBits* bits = nullptr; uint32_t entry_slot = vdb::NONE32; };
     void search_batch(const float* q, size_t nq, size_t top_k, size_t ef_search, const FilterArgs& fa,

@@ -358,6 +358,17 @@ __global__ void __launch_bounds__(64) merge_kernel(const vdb_scored_point* __res
 
 }  // namespace
 
+namespace {
+__global__ void __launch_bounds__(64) patch_blocks_kernel(uint32_t* __restrict__ adj0, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ blocks) {
+    adj0[(size_t)idx[blockIdx.x] * ADJ_BLOCK + threadIdx.x] = blocks[(size_t)blockIdx.x * ADJ_BLOCK + threadIdx.x];
+}
+}  // namespace
+void launch_patch_blocks(uint32_t* adj0, const uint32_t* idx, const uint32_t* blocks, uint32_t n, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(patch_blocks_kernel, dim3(n), dim3(64), 0, st, adj0, idx, blocks);
+    VDB_HIP(hipGetLastError());
+}
+
 uint32_t exact_knn_chunks(uint32_t n) { return std::max<uint32_t>(1, std::min<uint32_t>(64, (n + 4095) / 4096)); }
 
 void launch_exact_knn(const GraphView& g, const float* queries, uint32_t nq, uint32_t top_k, vdb_scored_point* out, uint32_t* out_n,

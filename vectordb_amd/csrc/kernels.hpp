@@ -94,6 +94,8 @@ void launch_normalize_rows(float* vecs, uint32_t stride, uint32_t dim, uint32_t 
 // Exact k-NN (strict arithmetic, (sort_key asc, id asc)) over live rows.
 void launch_exact_knn(const GraphView& g, const float* queries, uint32_t nq, uint32_t top_k, vdb_scored_point* out, uint32_t* out_n,
                       vdb_scored_point* scratch, uint32_t n_chunks, hipStream_t s);
+// adj0 block idx[i] <- blocks[i] (64 dwords each): device copy of the layer-0 lists edited on the host.
+void launch_patch_blocks(uint32_t* adj0, const uint32_t* idx, const uint32_t* blocks, uint32_t n, hipStream_t s);
 uint32_t exact_knn_chunks(uint32_t n);
 // FAST exact k-NN: fp32 MFMA candidate pass + strict re-rank (knn_mfma.hip).  scratch holds knn_mfma_scratch_words() dwords.
 bool knn_mfma_supported(const GraphView& g, uint32_t top_k);
