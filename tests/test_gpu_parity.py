@@ -294,6 +294,23 @@ def test_visited_table_overflow_is_finished_by_the_follow_up_launch(ora, vdb, mo
     assert _recall(big, bign, exact, exact_n, k) >= _recall(ref, refn, exact, exact_n, k) - 0.005
 
 
+@pytest.mark.parametrize("metric,d", [(2, 32), (0, 48), (1, 200)])
+def test_descent_as_its_own_launch_gives_the_same_results(ora, vdb, monkeypatch, metric, d):
+    """The upper-layer descent run as a separate launch (opt-in: VDB_SPLIT_DESCENT=1)
+    hands the beam the same layer-0 entries: outputs and counters of moves are identical."""
+    n, nq, k = 12000, 500, 10
+    h, x = build_oracle(ora, metric, n, d, seed=61 + metric, kind="clustered")
+    q = data(nq, d, 62, "clustered")
+    p = vdb.HNSWIndex(metric, 16, 64, 16, d); p.import_graph(h.export_graph())
+    monkeypatch.setenv("VDB_SPLIT_DESCENT", "0")
+    one, onen, st1 = p.search_batch(q, k, ef_search=96, with_stats=True)
+    monkeypatch.setenv("VDB_SPLIT_DESCENT", "1")
+    two, twon, st2 = p.search_batch(q, k, ef_search=96, with_stats=True)
+    assert np.array_equal(onen, twon)
+    assert np.array_equal(one["id"], two["id"]) and np.array_equal(one["sort_key"], two["sort_key"])
+    assert np.array_equal(st1["expanded"], st2["expanded"])          # same moves and expansions
+
+
 def test_exact_knn_ties_break_by_id(ora, vdb):
     d = 8
     base = np.zeros((40, d), np.float32); base[:, 0] = np.repeat(np.arange(10), 4)     # 4-way exact ties
@@ -347,3 +364,76 @@ def test_topk_merge_matches_oracle(ora, vdb):
     assert np.array_equal(refn, gotn)
     for q in range(Q):
         assert np.array_equal(ref[q][: refn[q]], got[q][: gotn[q]])
+
+
+def _payload_segment(api, metric, x, mode, arith=None):
+    kw = dict(seed=9, filter_mode=mode)
+    if arith is not None: kw["arith"] = arith
+    seg = api.Segment(api.HNSWIndex(metric, 8, 32, 16, x.shape[1], **kw))
+    for i in range(len(x)):
+        p = api.Payload(); p.set("cat", api.PayloadValue.Int(i % 20)); p.set("half", api.PayloadValue.Int(i % 2))
+        seg.insert(x[i], p)
+    return seg
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_masked_filter_mode_walks_the_graph_like_the_oracle(ora, vdb, monkeypatch, metric):
+    """Masked mode (the beam runs over every row, only passing rows enter the result list): same segment built by
+    single inserts on both sides, STRICT arithmetic -> identical results."""
+    n, d, k = 700, 16, 10
+    x = data(n, d, 81 + metric); q = data(25, d, 82)
+    so = _payload_segment(ora, metric, x, ora.FilterMode.Masked); so.set_filter_mode(ora.FilterMode.Masked)
+    sp = _payload_segment(vdb, metric, x, vdb.FilterMode.Masked, arith=vdb.Arith.Strict)
+    monkeypatch.setenv("VDB_MASKED_SCAN", "0")               # keep the graph walk even for narrow filters
+    for make in (lambda a: a.Filter.Match("half", a.PayloadValue.Int(1)),
+                 lambda a: a.Filter.Match("cat", a.PayloadValue.Int(3)),
+                 lambda a: a.Filter.And([a.Filter.Match("half", a.PayloadValue.Int(0)), a.Filter.Compare("cat", a.ScalarComparisonOp.Lt, a.PayloadValue.Int(9))])):
+        for qi in range(len(q)):
+            ref = so.in_place_filtered_search(q[qi], k, make(ora)); got = sp.in_place_filtered_search(q[qi], k, make(vdb))
+            assert [r.id for r in ref] == [g.id for g in got]
+            assert [np.float32(r.sort_key).view(np.uint32) for r in ref] == [np.float32(g.sort_key).view(np.uint32) for g in got]
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("arith", ["strict", "fast"])
+def test_masked_mode_scans_the_passing_rows_of_a_narrow_filter(ora, vdb, metric, arith):
+    """At most 1/8 of the rows pass: Masked mode returns the exact nearest passing rows (checked against the oracle's
+    brute force over an index that holds only the passing rows), tombstones excluded."""
+    n, d, k, nq = 900, 24, 10, 40
+    x = data(n, d, 91 + metric); q = data(nq, d, 92)
+    ar = vdb.Arith.Strict if arith == "strict" else vdb.Arith.Fast
+    seg = vdb.Segment(vdb.HNSWIndex(metric, 8, 32, 16, d, seed=3, filter_mode=vdb.FilterMode.Masked, arith=ar))
+    pay = []
+    for i in range(n):
+        p = vdb.Payload(); p.set("cat", vdb.PayloadValue.Int(i % 20)); pay.append(p)
+    ids = seg.insert_batch(x, pay)
+    passing = [i for i in range(n) if i % 20 == 3]
+    seg.delete(int(ids[passing[0]])); seg.delete(int(ids[passing[5]])); seg.delete(int(ids[7]))
+    live = [i for i in passing if i not in (passing[0], passing[5])]
+    ho = ora.HNSWIndex(metric, 8, 32, 16, d, seed=3)
+    for i in live: ho.insert(int(ids[i]), x[i])
+    ref, refn = ho.exact_knn_batch(q, k)
+    f = vdb.Filter.Match("cat", vdb.PayloadValue.Int(3))
+    got, gotn = seg.search_batch(q, k, filter=f)
+    bad = compare_results(ref, refn, got, gotn, exact=(arith == "strict"))
+    assert bad == 0
+    one = seg.search_with_filter(q[0], k, f)
+    assert [r.id for r in one] == got["id"][0][: gotn[0]].tolist()
+    wide = seg.in_place_filtered_search(q[1], 30, f)                      # more than the MFMA pass keeps per chunk
+    ref30, n30 = ho.exact_knn_batch(q[1:2], 30)
+    assert [r.id for r in wide] == ref30["id"][0][: n30[0]].tolist() or arith == "fast"
+    assert len(wide) == n30[0]
+
+
+def test_literal_filtered_search_reports_a_candidate_queue_that_is_too_small(vdb, monkeypatch):
+    """The literal walk keeps every scored row in its candidate queue; a queue that cannot hold them is an error
+    that names the way out, and with room for one entry per row the same call succeeds."""
+    n, d = 600, 8
+    x = data(n, d, 101)
+    seg = _payload_segment(vdb, 2, x, vdb.FilterMode.Literal)
+    f = vdb.Filter.Match("half", vdb.PayloadValue.Int(1))
+    full = seg.in_place_filtered_search(x[5], 10, f)
+    assert len(full) == 10
+    monkeypatch.setenv("VDB_LITERAL_CAND_CAP", "48")
+    with pytest.raises(vdb.DBError, match="VDB_FILTER_MASKED"):
+        seg.in_place_filtered_search(x[5], 10, f)

@@ -324,6 +324,22 @@ void vdb_index::run_search(SearchArgs a, size_t nq, hipStream_t s, bool retry_on
         VDB_HIP(hipStreamSynchronize(s));
     }
     a.spill_locks = s_spill.p; a.spill_pool = s_spill.p + a.spill_tables;
+    // Opt-in (VDB_SPLIT_DESCENT=1): the upper-layer descent as a launch of its own (a few hundred bytes
+    // of LDS per wavefront, so 28 are resident per CU), then the beam from the stored entries.  With
+    // batches on two streams the descent of one overlaps the beam of the other (+4 % at 1M x 128,
+    // 10k queries); a single stream gains nothing because the descent launch is bound by its own
+    // longest walks, so the default keeps one launch.
+    const char* se = getenv("VDB_SPLIT_DESCENT");
+    const bool split = reg_list_chunks(a) > 0 && a.mode == MODE_SEARCH && a.g.ublk && a.max_level >= 1 && !a.q_entry && a.stats &&
+                       se && atoi(se) != 0;
+    if (split) {
+        auto& eb = s_entry_by_stream[s];
+        eb.reserve(nq, s, false);
+        SearchArgs d = a; d.mode = MODE_DESCEND; d.entry_out = eb.p;
+        launch_search(d, s);
+        SearchArgs b = a; b.q_entry = eb.p;
+        launch_search(b, s);
+    } else
     launch_search(a, s);
     if (reg_list_chunks(a) > 0) {
         // The register-resident beam keeps its visited set in LDS alone and flags a query that fills
@@ -389,7 +405,13 @@ void vdb_index::search_batch(const float* q, size_t nq, size_t top_k, size_t ef_
     a.beam_width = beam_width();
     if (fa.bits) { a.pass_bits = fa.bits->d_pass.p; a.err_bits = fa.bits->d_err.p; }
     if (fa.mode == MODE_LITERAL) {
-        a.cand_cap = 16384;
+        // hnsw.rs:639-689 never prunes its candidate heap: it holds every scored row that was not popped yet,
+        // at most one entry per row.  The queue gets what 2 GiB of scratch allow per query, between 16384 and
+        // 262144 entries and never more than the rows there are; a walk that needs more is reported.
+        const char* ce = getenv("VDB_LITERAL_CAND_CAP");
+        size_t cap = std::min<size_t>(std::max<size_t>(((size_t)2 << 30) / (sizeof(vdb_scored_point) * nq), 16384), 262144);
+        if (ce && atoi(ce) > 0) cap = (size_t)atoi(ce);
+        a.cand_cap = (uint32_t)std::min<size_t>(cap, ids.size() + 1);
         s_cand.reserve(nq * a.cand_cap, stream, false);
         a.cand_scratch = s_cand.p;
     }
@@ -400,7 +422,10 @@ void vdb_index::search_batch(const float* q, size_t nq, size_t top_k, size_t ef_
     VDB_HIP(hipMemcpyAsync(st.data(), s_stats.p, nq * sizeof(vdb_query_stats), hipMemcpyDeviceToHost, stream));
     VDB_HIP(hipStreamSynchronize(stream));
     for (size_t i = 0; i < nq; ++i) {
-        if (st[i].flags & QF_CAND_OVERFLOW) throw Failure(err_device("filtered search candidate queue overflow"));
+        if (st[i].flags & QF_CAND_OVERFLOW)
+            throw Failure(err_device("literal filtered search: the candidate queue of query " + std::to_string(i) + " outgrew " + std::to_string(a.cand_cap) +
+                                     " entries (once ef passing rows are found the reference's walk scores every reachable row); "
+                                     "use fewer queries per call or VDB_FILTER_MASKED"));
         if (st[i].flags & QF_FILTER_ERROR) throw Failure(Error{VDB_ERR_INVALID_PAYLOAD, "@slot:" + std::to_string(st[i].expanded)});
     }
     if (stats) std::memcpy(stats, st.data(), nq * sizeof(vdb_query_stats));
@@ -451,6 +476,32 @@ void vdb_index::exact_knn(const float* q, size_t nq, size_t top_k, bool dev, vdb
     s_q.reserve(nq * dim, s, false); s_out.reserve(nq * top_k, s, false); s_n.reserve(nq, s, false);
     VDB_HIP(hipMemcpyAsync(s_q.p, q, nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
     run(s_q.p, s_out.p, s_n.p);
+    VDB_HIP(hipMemcpyAsync(out, s_out.p, nq * top_k * sizeof(vdb_scored_point), hipMemcpyDeviceToHost, s));
+    VDB_HIP(hipMemcpyAsync(out_n, s_n.p, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    VDB_HIP(hipStreamSynchronize(s));
+}
+
+void vdb_index::exact_knn_rows(const float* q, size_t nq, size_t top_k, const std::vector<uint32_t>& rows, vdb_scored_point* out, uint32_t* out_n) {
+    if (nq == 0) return;
+    if (rows.empty() || top_k == 0) { std::memset(out_n, 0, nq * sizeof(uint32_t)); return; }
+    std::lock_guard<std::mutex> lk(mu);
+    use_device();
+    hipStream_t s = stream;
+    sync_device();
+    const uint32_t p = (uint32_t)rows.size();
+    s_slots.reserve(p, s, false); s_sub_vecs.reserve((size_t)p * stride, s, false); s_sub_ids.reserve(p, s, false);
+    VDB_HIP(hipMemcpyAsync(s_slots.p, rows.data(), (size_t)p * 4, hipMemcpyHostToDevice, s));
+    GraphView g = view();
+    launch_gather_rows(g, s_slots.p, p, s_sub_vecs.p, s_sub_ids.p, s);
+    g.vecs = s_sub_vecs.p; g.ids = s_sub_ids.p; g.n = p; g.deleted = nullptr;
+    const bool mfma = opts.arith == VDB_ARITH_FAST && knn_mfma_supported(g, (uint32_t)top_k) && !std::getenv("VDB_KNN_STRICT");
+    const uint32_t chunks = exact_knn_chunks(p);
+    if (mfma) s_knn_words.reserve(knn_mfma_scratch_words(p, (uint32_t)nq), s, false);
+    else s_knn.reserve(nq * chunks * top_k, s, false);
+    s_q.reserve(nq * dim, s, false); s_out.reserve(nq * top_k, s, false); s_n.reserve(nq, s, false);
+    VDB_HIP(hipMemcpyAsync(s_q.p, q, nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
+    if (mfma) launch_exact_knn_mfma(g, s_q.p, (uint32_t)nq, (uint32_t)top_k, s_out.p, s_n.p, s_knn_words.p, s);
+    else launch_exact_knn(g, s_q.p, (uint32_t)nq, (uint32_t)top_k, s_out.p, s_n.p, s_knn.p, chunks, s);
     VDB_HIP(hipMemcpyAsync(out, s_out.p, nq * top_k * sizeof(vdb_scored_point), hipMemcpyDeviceToHost, s));
     VDB_HIP(hipMemcpyAsync(out_n, s_n.p, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     VDB_HIP(hipStreamSynchronize(s));

@@ -45,6 +45,7 @@ struct FilterBits {                      // a Filter compiled against the segmen
     std::vector<uint32_t> pass, err;     // per slot; missing payload / Err -> pass = 0
     DevBuf<uint32_t> d_pass, d_err;
     size_t n_pass = 0, n_err = 0; uint64_t version = 0;
+    std::vector<uint32_t> live_pass;     // passing slots that are not tombstoned, ascending
 };
 
 }  // namespace vdb
@@ -75,9 +76,10 @@ struct vdb_index {
     size_t l0_edges = 0, upper_edges = 0, device_bytes = 0, l0_edges_acc = 0;
     // per-call scratch (guarded by mu)
     mutable std::mutex mu;
-    mutable vdb::DevBuf<float> s_q, s_raw; mutable vdb::DevBuf<vdb_scored_point> s_out, s_knn, s_cand;
+    mutable vdb::DevBuf<float> s_q, s_raw, s_sub_vecs; mutable vdb::DevBuf<uint64_t> s_sub_ids; mutable vdb::DevBuf<vdb_scored_point> s_out, s_knn, s_cand;
     mutable vdb::DevBuf<uint32_t> s_knn_words, s_n, s_slots, s_lvl, s_off, s_nb, s_nbc, s_hash, s_spill; mutable vdb::DevBuf<vdb_query_stats> s_stats;
     mutable std::map<hipStream_t, vdb::DevBuf<vdb_query_stats>> s_stats_by_stream;
+    mutable std::map<hipStream_t, vdb::DevBuf<uint32_t>> s_entry_by_stream;     // layer-0 entries between the two search launches
 
     vdb_index(vdb_metric metric, size_t m, size_t ef, size_t cap, size_t dim, const vdb_options& o);
     ~vdb_index();
@@ -109,6 +111,8 @@ struct vdb_index {
     void search_batch_dev(const float* d_q, size_t nq, size_t top_k, size_t ef_search, vdb_scored_point* d_out, uint32_t* d_out_n,
                           vdb_query_stats* d_stats, hipStream_t s);
     void exact_knn(const float* q, size_t nq, size_t top_k, bool dev, vdb_scored_point* out, uint32_t* out_n, hipStream_t s);
+    // exact k-NN restricted to `rows` (live slots): the rows are gathered into a dense table first
+    void exact_knn_rows(const float* q, size_t nq, size_t top_k, const std::vector<uint32_t>& rows, vdb_scored_point* out, uint32_t* out_n);
     std::vector<float> score_rows(uint32_t query_slot, const std::vector<uint32_t>& slots);
     std::vector<float> score_all_rows(uint32_t query_slot);
     std::vector<vdb_scored_point> search_from_row(uint32_t row_slot, uint32_t entry_slot, size_t ef_search);
@@ -149,7 +153,8 @@ struct vdb_segment {
     void build_filter_aware_edges(uint64_t id, const vdb_payload& p, const std::vector<std::string>& keys);
 
  private:
-    void filtered_batch(const float* q, size_t nq, size_t len, size_t top_k, size_t ef_search, const vdb_filter* f,
+    // useful_k: leading results the caller keeps when none of them is a tombstone (top_k may be an over-fetch)
+    void filtered_batch(const float* q, size_t nq, size_t len, size_t top_k, size_t useful_k, size_t ef_search, const vdb_filter* f,
                         vdb_scored_point* out, uint32_t* out_n) const;
     std::optional<uint64_t> find_entry_point_matching_filter(const vdb_filter& f) const;
 };

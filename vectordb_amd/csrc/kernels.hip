@@ -11,11 +11,13 @@ void launch_search_plain(const SearchArgs& a, size_t lds, hipStream_t st);
 void launch_search_build(const SearchArgs& a, size_t lds, hipStream_t st);
 void launch_search_masked(const SearchArgs& a, size_t lds, hipStream_t st);
 void launch_search_literal(const SearchArgs& a, size_t lds, hipStream_t st);
+void launch_search_descend(const SearchArgs& a, size_t lds, hipStream_t st);
 
 size_t search_lds_bytes(const SearchArgs& a) {
     const size_t ef_cap = (a.ef + 63u) & ~63u;
     const size_t nc = reg_list_chunks(a), hash = (size_t)4 << a.hash_log2, row = (size_t)a.g.stride * 4;
     const size_t staging = (nc ? 256 : 64) * 8;      // cand + craw
+    if (a.mode == MODE_DESCEND) return staging + row;
     const size_t tags = nc ? ((size_t)2 << a.tag_log2) + 512 * 4 : 0;   // 16-bit visited table + secondary table
     if (nc && a.mode == MODE_SEARCH) return ((std::max(std::max(nc * 512, row), staging) + 15) & ~(size_t)15) + tags;   // one shared staging area
     return ef_cap * 16 + (a.mode == MODE_MASKED ? ef_cap * 16 : 0) + nc * 512 + tags + staging + row + hash;
@@ -29,6 +31,7 @@ void launch_search(const SearchArgs& a, hipStream_t st) {
         case MODE_BUILD: launch_search_build(a, lds, st); break;
         case MODE_MASKED: launch_search_masked(a, lds, st); break;
         case MODE_LITERAL: launch_search_literal(a, lds, st); break;
+        case MODE_DESCEND: launch_search_descend(a, lds, st); break;
         default: launch_search_plain(a, lds, st); break;
     }
     VDB_HIP(hipGetLastError());
@@ -366,6 +369,26 @@ __global__ void __launch_bounds__(64) patch_blocks_kernel(uint32_t* __restrict__
 void launch_patch_blocks(uint32_t* adj0, const uint32_t* idx, const uint32_t* blocks, uint32_t n, hipStream_t st) {
     if (n == 0) return;
     hipLaunchKernelGGL(patch_blocks_kernel, dim3(n), dim3(64), 0, st, adj0, idx, blocks);
+    VDB_HIP(hipGetLastError());
+}
+
+namespace {
+// one wave per gathered row, 16 bytes per lane and trip
+__global__ void __launch_bounds__(256) gather_rows_kernel(GraphView g, const uint32_t* __restrict__ slots, uint32_t n,
+                                                          float* __restrict__ out_vecs, uint64_t* __restrict__ out_ids) {
+    const uint32_t row = blockIdx.x * 4 + threadIdx.x / WAVE;
+    if (row >= n) return;
+    const int lane = lane_id();
+    const uint32_t s = slots[row];
+    const float4* src = reinterpret_cast<const float4*>(g.vecs + (size_t)s * g.stride);
+    float4* dst = reinterpret_cast<float4*>(out_vecs + (size_t)row * g.stride);
+    for (uint32_t c = lane; c < g.stride / 4; c += WAVE) dst[c] = src[c];
+    if (lane == 0) out_ids[row] = g.ids[s];
+}
+}  // namespace
+void launch_gather_rows(const GraphView& g, const uint32_t* slots, uint32_t n, float* out_vecs, uint64_t* out_ids, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, st, g, slots, n, out_vecs, out_ids);
     VDB_HIP(hipGetLastError());
 }
 

@@ -35,7 +35,8 @@ struct GraphView {
     int metric;
 };
 
-enum SearchMode : int { MODE_SEARCH = 0, MODE_BUILD = 1, MODE_MASKED = 2, MODE_LITERAL = 3 };
+// MODE_DESCEND runs only the upper-layer descent of MODE_SEARCH and stores each query's layer-0 entry.
+enum SearchMode : int { MODE_SEARCH = 0, MODE_BUILD = 1, MODE_MASKED = 2, MODE_LITERAL = 3, MODE_DESCEND = 4 };
 
 struct SearchArgs {
     GraphView g;
@@ -66,7 +67,9 @@ struct SearchArgs {
     // MODE_MASKED / MODE_LITERAL
     const uint32_t* pass_bits;   // filter passes (errors count as false)
     const uint32_t* err_bits;    // evaluate_filter returned Err
-    const uint32_t* q_entry;     // MODE_LITERAL: per-query entry (nullptr: args.entry)
+    const uint32_t* q_entry;     // MODE_LITERAL: per-query entry (nullptr: args.entry); MODE_SEARCH: layer-0 entries of an
+                                 // earlier MODE_DESCEND launch (its counters in `stats` are carried on)
+    uint32_t* entry_out;         // MODE_DESCEND: nq layer-0 entries
     vdb_scored_point* cand_scratch;   // MODE_LITERAL: nq x cand_cap candidate queue
     uint32_t cand_cap;
 };
@@ -96,6 +99,8 @@ void launch_exact_knn(const GraphView& g, const float* queries, uint32_t nq, uin
                       vdb_scored_point* scratch, uint32_t n_chunks, hipStream_t s);
 // adj0 block idx[i] <- blocks[i] (64 dwords each): device copy of the layer-0 lists edited on the host.
 void launch_patch_blocks(uint32_t* adj0, const uint32_t* idx, const uint32_t* blocks, uint32_t n, hipStream_t s);
+// out_vecs row j <- row slots[j] of the table (stride floats), out_ids[j] <- its PointId.
+void launch_gather_rows(const GraphView& g, const uint32_t* slots, uint32_t n, float* out_vecs, uint64_t* out_ids, hipStream_t s);
 uint32_t exact_knn_chunks(uint32_t n);
 // FAST exact k-NN: fp32 MFMA candidate pass + strict re-rank (knn_mfma.hip).  scratch holds knn_mfma_scratch_words() dwords.
 bool knn_mfma_supported(const GraphView& g, uint32_t top_k);

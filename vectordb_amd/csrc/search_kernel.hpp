@@ -737,7 +737,11 @@ struct Searcher {
         // ---- carve LDS (every offset a multiple of 16 bytes) ----
         const uint32_t ef_cap = (a.ef + 63u) & ~63u;
         size_t off = 0;
-        if (NC > 0 && MODE == MODE_SEARCH) {
+        if (MODE == MODE_DESCEND) {
+            cand = reinterpret_cast<uint32_t*>(smem); craw = reinterpret_cast<float*>(smem + CAND_CAP * 4);
+            qlds = reinterpret_cast<float*>(smem + CAND_CAP * 8);
+            off = (size_t)CAND_CAP * 8 + (size_t)gv.stride * 4;
+        } else if (NC > 0 && MODE == MODE_SEARCH) {
             // register-resident list: LDS only stages permutations, the query (until it is in
             // registers) and the final list, all in one area
             // (candidate ids + scores, then the permutation of the merge, which has read them into registers)
@@ -828,9 +832,17 @@ struct Searcher {
                 wave_sync();
             }
             if (a.out && !(flags & QF_HASH_OVERFLOW)) emit(q, R, false);                // layer-0 beam, full list
+        } else if (MODE == MODE_DESCEND) {
+            uint32_t cur = a.entry;
+            uint32_t ref = make_uref(gv.upper_base[cur], gv.upper_cnt[cur]); float kc = 0.f; bool hc = false;
+            for (uint32_t l = a.max_level; l >= 1; --l) cur = greedy_fused(cur, ref, l, kc, hc);
+            if (lane == 0) a.entry_out[q] = cur;
         } else {
             uint32_t cur = a.entry;
-            if (gv.ublk) {
+            if (MODE == MODE_SEARCH && a.q_entry) {                         // descent done by an earlier launch
+                cur = a.q_entry[q];
+                if (a.stats) { rows_scored = a.stats[q].rows_scored; expanded = a.stats[q].expanded; adj_entries = a.stats[q].adj_entries; }
+            } else if (gv.ublk) {
                 uint32_t ref = make_uref(gv.upper_base[cur], gv.upper_cnt[cur]); float kc = 0.f; bool hc = false;
                 for (uint32_t l = a.max_level; l >= 1; --l) cur = greedy_fused(cur, ref, l, kc, hc);
             } else
@@ -848,7 +860,7 @@ struct Searcher {
 #ifdef VDB_TIMING
         // diagnostic build only: adj_entries carries the wavefront's lifetime in 10 ns ticks, rows_scored its start tick
         adj_entries = (uint32_t)(wall_clock64() - t_begin); rows_scored = (uint32_t)t_begin;
-        if (lane == 0 && a.out && a.top_k >= 5) {      // phase totals overwrite this query's result records
+        if (lane == 0 && a.out && a.top_k >= 5 && MODE != MODE_DESCEND) {      // phase totals overwrite this query's result records
             unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.out + (size_t)q * a.top_k);
             tacc[9] -= t_begin; tacc[5] = wall_clock64() - t_begin;
             for (int i = 0; i < 10; ++i) dbg[i] = tacc[i];

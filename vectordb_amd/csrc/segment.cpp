@@ -221,12 +221,12 @@ const FilterBits& vdb_segment::compile(const vdb_filter& f) const {
     if (slot && slot->version == payload_version && slot->pass.size() == (n + 31) / 32) return *slot;
     if (!slot) slot = std::make_unique<FilterBits>();
     FilterBits& fb = *slot;
-    fb.pass.assign((n + 31) / 32, 0); fb.err.assign((n + 31) / 32, 0); fb.n_pass = fb.n_err = 0;
+    fb.pass.assign((n + 31) / 32, 0); fb.err.assign((n + 31) / 32, 0); fb.n_pass = fb.n_err = 0; fb.live_pass.clear();
     for (size_t s = 0; s < n; ++s) {
         auto pit = payloads.find(hnsw->ids[s]);
         if (pit == payloads.end()) continue;
         const Tri t = f.eval(pit->second);
-        if (t.s == Tri::True) { fb.pass[s >> 5] |= 1u << (s & 31); if (!hnsw->deleted[s]) ++fb.n_pass; }
+        if (t.s == Tri::True) { fb.pass[s >> 5] |= 1u << (s & 31); if (!hnsw->deleted[s]) { ++fb.n_pass; fb.live_pass.push_back((uint32_t)s); } }
         else if (t.s == Tri::Err) { fb.err[s >> 5] |= 1u << (s & 31); if (!hnsw->deleted[s]) ++fb.n_err; }
     }
     hnsw->use_device();
@@ -241,7 +241,15 @@ const FilterBits& vdb_segment::compile(const vdb_filter& f) const {
     return fb;
 }
 
-void vdb_segment::filtered_batch(const float* q, size_t nq, size_t len, size_t top_k, size_t ef_search, const vdb_filter* f,
+// Masked mode: when at most this fraction of the rows passes, the passing rows are scanned exactly
+// instead of walking the graph (a beam of fixed width meets too few passing rows to fill top_k).
+static bool masked_scan_pays(size_t n_pass, size_t n) {
+    const char* e = std::getenv("VDB_MASKED_SCAN");               // 0: never, 1: always
+    if (e) return std::atoi(e) != 0;
+    return n_pass <= 4096 || n_pass * 8 <= n;
+}
+
+void vdb_segment::filtered_batch(const float* q, size_t nq, size_t len, size_t top_k, size_t useful_k, size_t ef_search, const vdb_filter* f,
                                  vdb_scored_point* out, uint32_t* out_n) const {
     vdb_index& h = *hnsw;
     if (len != h.dim) throw Failure(err_length_mismatch(h.dim, len));               // hnsw.rs:593-598
@@ -249,6 +257,15 @@ void vdb_segment::filtered_batch(const float* q, size_t nq, size_t len, size_t t
     const FilterBits* bits = f ? &compile(*f) : nullptr;
     fa.bits = bits;
     if (h.opts.filter_mode == VDB_FILTER_MASKED) {
+        if (f && masked_scan_pays(bits->n_pass, h.len())) {
+            // the scan returns no tombstone, so the caller's over-fetch is not needed; rows of out stay top_k apart
+            const size_t k = std::min(top_k, useful_k);
+            if (k == top_k) { h.exact_knn_rows(q, nq, k, bits->live_pass, out, out_n); return; }
+            std::vector<vdb_scored_point> tmp(nq * k);
+            h.exact_knn_rows(q, nq, k, bits->live_pass, tmp.data(), out_n);
+            for (size_t i = 0; i < nq; ++i) std::memcpy(out + i * top_k, tmp.data() + i * k, out_n[i] * sizeof(vdb_scored_point));
+            return;
+        }
         fa.mode = f ? MODE_MASKED : MODE_SEARCH;
         h.search_batch(q, nq, top_k, ef_search, fa, out, out_n, nullptr);
         return;
@@ -291,7 +308,7 @@ std::vector<vdb_scored_point> vdb_segment::in_place_filtered_search(const float*
     std::vector<vdb_scored_point> out(std::max<size_t>(top_k, 1));
     uint32_t n = 0;
     if (top_k == 0) return {};
-    filtered_batch(q, 1, len, top_k, 0, f, out.data(), &n);
+    filtered_batch(q, 1, len, top_k, top_k, 0, f, out.data(), &n);
     out.resize(n);
     return out;
 }
@@ -329,7 +346,7 @@ void vdb_segment::search_batch(const float* q, size_t nq, size_t len, size_t top
     const size_t k2 = top_k * 2;
     std::vector<vdb_scored_point> tmp(nq * std::max<size_t>(k2, 1)); std::vector<uint32_t> cnt(nq, 0);
     if (k2) {
-        if (f) filtered_batch(q, nq, len, k2, ef_search, f, tmp.data(), cnt.data());
+        if (f) filtered_batch(q, nq, len, k2, top_k, ef_search, f, tmp.data(), cnt.data());
         else hnsw->search_batch(q, nq, k2, ef_search, {}, tmp.data(), cnt.data(), nullptr);
     }
     for (size_t i = 0; i < nq; ++i) {
