@@ -265,6 +265,17 @@ vdb_status vdb_index_import_graph(vdb_index* x, size_t n, const uint64_t* ids, c
 vdb_status vdb_index_export_sizes(const vdb_index* x, size_t* n, size_t* n_layers, size_t* n_lists, size_t* n_edges, size_t cap_layers);
 vdb_status vdb_index_export_points(const vdb_index* x, uint64_t* ids, uint32_t* levels, float* vectors, uint8_t* deleted);
 vdb_status vdb_index_export_layer(const vdb_index* x, size_t level, uint32_t* owners, uint64_t* offsets, uint32_t* neighbors);
+/* Graph file (extension; the reference keeps nothing on disk, README.md:32).  One little-endian
+ * file, every array padded to a multiple of 8 bytes:
+ *   header, 112 bytes: char magic[8] = "VDBGRAF1"; u32 version = 1; u32 metric; u64 m, ef,
+ *     max_level_cap, dim, n, n_layers; u64 has_entry, entry_id, current_max_level; u64 level_draws,
+ *     sample_draws (positions of the two counter-based random streams); u64 seed
+ *   u64 ids[n]; u32 levels[n]; u8 deleted[n]; f32 vectors[n * dim] (stored form)
+ *   per layer: u64 n_lists, n_edges; u32 owners[n_lists]; u64 offsets[n_lists + 1];
+ *     u32 neighbors[n_edges]                       (the arrays of vdb_index_export_layer)
+ * load replaces the contents of an index created with the same metric and dimension. */
+vdb_status vdb_index_save(const vdb_index* x, const char* path);
+vdb_status vdb_index_load(vdb_index* x, const char* path);
 /* Device-side footprint of the packed graph actually searched (after self-loop / duplicate removal). */
 vdb_status vdb_index_device_info(const vdb_index* x, size_t* n_slots, size_t* row_stride_floats,
                                  size_t* l0_edges, size_t* upper_edges, size_t* bytes_total);

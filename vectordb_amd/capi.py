@@ -179,6 +179,7 @@ _SIGS = {
     "index_export_layer": (_I, [_VP, _SZ, _VP, _VP, _VP]),
     "index_device_info": (_I, [_VP, _PSZ, _PSZ, _PSZ, _PSZ, _PSZ]),
     "index_sync_device": (_I, [_VP]),
+    "index_save": (_I, [_VP, C.c_char_p]), "index_load": (_I, [_VP, C.c_char_p]),
     "segment_new": (_I, [_VP, C.POINTER(_VP)]), "segment_free": (None, [_VP]),
     "segment_insert": (_I, [_VP, _VP, _SZ, _VP, C.POINTER(_U64)]),
     "segment_insert_batch": (_I, [_VP, _VP, _SZ, _SZ, _VP, _VP]),
@@ -469,6 +470,22 @@ def bind(cdll, prefix="vdb_", required=None):
                 layers.append((ow, of, nb[: int(edges[l])]))
             return dict(ids=ids, levels=lv, vectors=vec, deleted=dl, layers=layers,
                         entry=self.get_entry_point(), current_max_level=self.current_max_level())
+
+        def save(self, path):
+            """One graph file (layout: include/vdbmi.h); a backend without the entry point writes it from export_graph()."""
+            if hasattr(fn, "index_save"):
+                check(fn.index_save(self._h, str(path).encode())); return
+            from . import graph_file
+            graph_file.write_graph(path, self.export_graph(), metric=int(self.metric()), m=self.m(), ef=self.ef(),
+                                   max_level_cap=self.max_level_cap())
+        def load(self, path):
+            if hasattr(fn, "index_load"):
+                check(fn.index_load(self._h, str(path).encode())); return
+            from . import graph_file
+            cfg, g = graph_file.read_graph(path)
+            if cfg["metric"] != int(self.metric()) or cfg["dim"] != self.dim():
+                raise ArgumentError(f"{path} holds metric {cfg['metric']}, dimension {cfg['dim']}")
+            self.import_graph(g)
 
         def import_graph(self, g):
             ids = np.ascontiguousarray(g["ids"], np.uint64); lv = np.ascontiguousarray(g["levels"], np.uint32)

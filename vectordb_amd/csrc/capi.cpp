@@ -1,4 +1,5 @@
 // extern "C" surface of libvdbmi (declarations and reference citations: include/vdbmi.h).
+#include <cstdio>
 #include <cstring>
 
 #include "index.hpp"
@@ -312,6 +313,80 @@ vdb_status vdb_index_export_layer(const vdb_index* x, size_t level, uint32_t* ow
             for (uint32_t s : L.lists[order[k]]) neighbors[off++] = s;
         }
         offsets[order.size()] = off;
+    });
+}
+// ---- graph file (layout in vdbmi.h) ----
+namespace {
+constexpr char GRAPH_MAGIC[8] = {'V', 'D', 'B', 'G', 'R', 'A', 'F', '1'};
+struct GraphFileHeader {
+    char magic[8]; uint32_t version, metric; uint64_t m, ef, max_level_cap, dim, n, n_layers;
+    uint64_t has_entry, entry_id, current_max_level, level_draws, sample_draws, seed;
+};
+static_assert(sizeof(GraphFileHeader) == 112, "graph file header is 112 bytes");
+struct File {
+    FILE* f; std::string path;
+    File(const char* p, const char* mode) : f(std::fopen(p, mode)), path(p) { if (!f) throw Failure(err_arg("cannot open " + path)); }
+    ~File() { if (f) std::fclose(f); }
+    void put(const void* d, size_t bytes) {
+        if (bytes && std::fwrite(d, 1, bytes, f) != bytes) throw Failure(err_arg("short write to " + path));
+        static const char zero[8] = {0};
+        if (bytes % 8 && std::fwrite(zero, 1, 8 - bytes % 8, f) != 8 - bytes % 8) throw Failure(err_arg("short write to " + path));
+    }
+    void get(void* d, size_t bytes) {
+        if (bytes && std::fread(d, 1, bytes, f) != bytes) throw Failure(err_arg(path + " is truncated"));
+        char pad[8];
+        if (bytes % 8 && std::fread(pad, 1, 8 - bytes % 8, f) != 8 - bytes % 8) throw Failure(err_arg(path + " is truncated"));
+    }
+};
+}  // namespace
+vdb_status vdb_index_save(const vdb_index* x, const char* path) {
+    return guard([&] {
+        need(x, "index"); need(path, "path");
+        File out(path, "wb");
+        GraphFileHeader h{};
+        std::memcpy(h.magic, GRAPH_MAGIC, 8); h.version = 1; h.metric = (uint32_t)x->metric;
+        h.m = x->m; h.ef = x->ef; h.max_level_cap = x->max_level_cap; h.dim = x->dim; h.n = x->len(); h.n_layers = x->layers.size();
+        h.has_entry = x->entry_point ? 1 : 0; h.entry_id = x->entry_point ? *x->entry_point : 0; h.current_max_level = x->current_max_level;
+        h.level_draws = x->level_draws; h.sample_draws = x->sample_draws; h.seed = x->opts.seed;
+        out.put(&h, sizeof h);
+        out.put(x->ids.data(), h.n * 8); out.put(x->levels.data(), h.n * 4); out.put(x->deleted.data(), h.n);
+        out.put(x->hvecs.data(), h.n * x->dim * 4);
+        for (size_t l = 0; l < x->layers.size(); ++l) {
+            size_t n_lists = 0, n_edges = 0;
+            n_lists = x->layers[l].lists.size(); for (auto& v : x->layers[l].lists) n_edges += v.size();
+            std::vector<uint32_t> owners(n_lists), nb(std::max<size_t>(n_edges, 1)); std::vector<uint64_t> off(n_lists + 1);
+            if (vdb_index_export_layer(x, l, owners.data(), off.data(), nb.data()) != VDB_OK) throw Failure(err_arg(vdb_last_error_message()));
+            const uint64_t cnt[2] = {n_lists, n_edges};
+            out.put(cnt, 16); out.put(owners.data(), n_lists * 4); out.put(off.data(), (n_lists + 1) * 8); out.put(nb.data(), n_edges * 4);
+        }
+        if (std::fflush(out.f) != 0) throw Failure(err_arg("short write to " + out.path));
+    });
+}
+vdb_status vdb_index_load(vdb_index* x, const char* path) {
+    return guard([&] {
+        need(x, "index"); need(path, "path");
+        File in(path, "rb");
+        GraphFileHeader h{};
+        in.get(&h, sizeof h);
+        if (std::memcmp(h.magic, GRAPH_MAGIC, 8) != 0 || h.version != 1) throw Failure(err_arg(in.path + " is not a version-1 graph file"));
+        if (h.metric != (uint32_t)x->metric || h.dim != x->dim)
+            throw Failure(err_arg(in.path + " holds metric " + std::to_string(h.metric) + ", dimension " + std::to_string(h.dim) + "; the index was created with metric " +
+                                  std::to_string((int)x->metric) + ", dimension " + std::to_string(x->dim)));
+        if (h.n > 0xFFFFFFF0ull || h.n_layers > 64) throw Failure(err_arg(in.path + " has an implausible header"));
+        std::vector<uint64_t> ids(h.n); std::vector<uint32_t> levels(h.n); std::vector<uint8_t> del(h.n); std::vector<float> vecs(h.n * h.dim);
+        in.get(ids.data(), h.n * 8); in.get(levels.data(), h.n * 4); in.get(del.data(), h.n); in.get(vecs.data(), h.n * h.dim * 4);
+        std::vector<std::vector<uint32_t>> owners(h.n_layers), nbs(h.n_layers); std::vector<std::vector<uint64_t>> offs(h.n_layers);
+        std::vector<vdb_layer_csr> csr(h.n_layers);
+        for (size_t l = 0; l < h.n_layers; ++l) {
+            uint64_t cnt[2]; in.get(cnt, 16);
+            if (cnt[0] > h.n || cnt[1] > (uint64_t)1 << 40) throw Failure(err_arg(in.path + ": layer " + std::to_string(l) + " has implausible sizes"));
+            owners[l].resize(cnt[0]); offs[l].resize(cnt[0] + 1); nbs[l].resize(cnt[1]);
+            in.get(owners[l].data(), cnt[0] * 4); in.get(offs[l].data(), (cnt[0] + 1) * 8); in.get(nbs[l].data(), cnt[1] * 4);
+            if (offs[l].back() != cnt[1]) throw Failure(err_arg(in.path + ": layer " + std::to_string(l) + " offsets do not cover its neighbours"));
+            csr[l] = {(size_t)cnt[0], owners[l].data(), offs[l].data(), nbs[l].data()};
+        }
+        x->import_graph(h.n, ids.data(), levels.data(), vecs.data(), del.data(), h.n_layers, csr.data(), h.has_entry != 0, h.entry_id, h.current_max_level);
+        x->level_draws = h.level_draws; x->sample_draws = h.sample_draws;
     });
 }
 vdb_status vdb_index_device_info(const vdb_index* x, size_t* n_slots, size_t* row_stride_floats, size_t* l0_edges, size_t* upper_edges, size_t* bytes_total) {

@@ -1,0 +1,71 @@
+"""Reader and writer of the graph file that `vdb_index_save` / `vdb_index_load` use (layout: include/vdbmi.h).
+
+Works on the dictionaries of `HNSWIndex.export_graph()` / `import_graph()`, so a graph built by any
+backend that exposes those two calls can be shipped as one file and loaded by the GPU library.
+The reference keeps nothing on disk (README.md:32); the format exists for fixtures and hand-over.
+"""
+from __future__ import annotations
+
+import struct
+
+import numpy as np
+
+MAGIC = b"VDBGRAF1"
+_HEADER = struct.Struct("<8sII" + "Q" * 12)          # 112 bytes
+
+
+def _pad(f, nbytes):
+    if nbytes % 8:
+        f.write(b"\0" * (8 - nbytes % 8))
+
+
+def _put(f, arr, dtype):
+    a = np.ascontiguousarray(arr, dtype=dtype)
+    f.write(a.tobytes()); _pad(f, a.nbytes)
+
+
+def _get(f, count, dtype):
+    nbytes = count * np.dtype(dtype).itemsize
+    raw = f.read(nbytes)
+    if len(raw) != nbytes:
+        raise ValueError("graph file is truncated")
+    if nbytes % 8:
+        f.read(8 - nbytes % 8)
+    return np.frombuffer(raw, dtype=dtype).copy()
+
+
+def write_graph(path, g, *, metric, m, ef, max_level_cap, seed=0, level_draws=0, sample_draws=0):
+    """g: dict(ids, levels, vectors, deleted, layers=[(owners, offsets, neighbors)], entry, current_max_level)."""
+    vec = np.ascontiguousarray(g["vectors"], np.float32)
+    n = len(g["ids"]); dim = vec.shape[1] if vec.ndim == 2 else 0
+    entry = g["entry"]
+    with open(path, "wb") as f:
+        f.write(_HEADER.pack(MAGIC, 1, int(metric), m, ef, max_level_cap, dim, n, len(g["layers"]),
+                             0 if entry is None else 1, 0 if entry is None else int(entry), int(g["current_max_level"]),
+                             level_draws, sample_draws, seed))
+        _put(f, g["ids"], np.uint64); _put(f, g["levels"], np.uint32); _put(f, g["deleted"], np.uint8); _put(f, vec, np.float32)
+        for owners, offsets, neighbors in g["layers"]:
+            f.write(struct.pack("<QQ", len(owners), len(neighbors)))
+            _put(f, owners, np.uint32); _put(f, offsets, np.uint64); _put(f, neighbors, np.uint32)
+
+
+def read_graph(path):
+    """-> (config dict, graph dict as import_graph takes it)."""
+    with open(path, "rb") as f:
+        raw = f.read(_HEADER.size)
+        if len(raw) != _HEADER.size:
+            raise ValueError("graph file is truncated")
+        (magic, version, metric, m, ef, cap, dim, n, n_layers, has_entry, entry, cur_max, level_draws, sample_draws,
+         seed) = _HEADER.unpack(raw)
+        if magic != MAGIC or version != 1:
+            raise ValueError("not a version-1 graph file")
+        ids = _get(f, n, np.uint64); levels = _get(f, n, np.uint32); deleted = _get(f, n, np.uint8)
+        vectors = _get(f, n * dim, np.float32).reshape(n, dim)
+        layers = []
+        for _ in range(n_layers):
+            n_lists, n_edges = struct.unpack("<QQ", f.read(16))
+            layers.append((_get(f, n_lists, np.uint32), _get(f, n_lists + 1, np.uint64), _get(f, n_edges, np.uint32)))
+    cfg = dict(metric=metric, m=m, ef=ef, max_level_cap=cap, dim=dim, seed=seed, level_draws=level_draws, sample_draws=sample_draws)
+    g = dict(ids=ids, levels=levels, vectors=vectors, deleted=deleted, layers=layers,
+             entry=entry if has_entry else None, current_max_level=cur_max)
+    return cfg, g
