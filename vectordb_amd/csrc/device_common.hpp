@@ -384,14 +384,16 @@ struct Visited {
     }
 };
 
-// Visited set of the register-resident beam: exact, 16 bits per id.  An id below 2^(bbits + 15) is
-// mapped one-to-one (odd multiplier modulo a power of two) onto a bucket number (bbits) and a 15-bit
-// tag; a bucket is 16 bytes = eight tags (bit 15 marks a used entry), filled front to back and never
-// emptied, so one ds_read_b128 shows whether the id is present and where the first free entry is.
-// Ids whose bucket is full go to a small secondary table of whole ids (Visited layout).
+// Visited set of the register-resident beam, 16 bits per id.  An id below 2^(bbits + 15) is mapped
+// one-to-one (odd multiplier modulo a power of two) onto a bucket number (bbits) and a 15-bit tag, so
+// "present" is never wrong; a bucket is 16 bytes = eight tags (bit 15 marks a used entry), filled
+// front to back, and one ds_read_b128 shows whether the id is present and where the first free entry
+// is.  An id that meets a full bucket replaces one of its eight tags: the set may FORGET an id, never
+// invent one.  A forgotten id that turns up again is scored again and then either fails the
+// admission test it failed before (the bound only tightens) or is found in the result list by its
+// key and id (the merge drops it), so results do not depend on what was forgotten — only the work does.
 struct TagSet {
     uint32_t* tab; uint32_t idmask;
-    uint32_t* sec; uint32_t smask, sshift;
     static constexpr uint32_t MUL = 2654435761u, USED = 0x80008000u;
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     static __device__ __forceinline__ uint32_t pkmin(uint32_t a, uint32_t b) {
@@ -410,13 +412,17 @@ struct TagSet {
     static __device__ __forceinline__ uint32_t used(const uint4 v) {
         return __popc(v.x & USED) + __popc(v.y & USED) + __popc(v.z & USED) + __popc(v.w & USED);
     }
-    // CAS operands that put `tag` into entry u (< 8) of bucket v
-    static __device__ __forceinline__ void slot_of(const uint4 v, uint32_t u, uint32_t tag, uint32_t& widx, uint32_t& expect, uint32_t& desired) {
-        widx = u >> 1;
+    // Entry that takes `tag` in a bucket with u used entries: the first free one, or, in a full
+    // bucket, the entry three bits of the tag pick (its id is forgotten).
+    static __device__ __forceinline__ uint32_t entry_for(uint32_t u, uint32_t tag) { return u < 8u ? u : ((tag >> 5) & 7u); }
+    // CAS operands that put `tag` into entry e (< 8) of bucket v
+    static __device__ __forceinline__ void slot_of(const uint4 v, uint32_t e, uint32_t tag, uint32_t& widx, uint32_t& expect, uint32_t& desired) {
+        widx = e >> 1;
         expect = widx == 0 ? v.x : widx == 1 ? v.y : widx == 2 ? v.z : v.w;
-        desired = expect | (tag << ((u & 1u) * 16u));
+        const uint32_t sh = (e & 1u) * 16u;
+        desired = (expect & ~(0xFFFFu << sh)) | (tag << sh);
     }
-    // Generic insert: 0 = the id was already in the set, 1 = added to the tag table, 2 = added to the secondary table.
+    // Generic insert: 0 = the id was already in the set, 1 = added, 2 = added in place of another id.
     __device__ __forceinline__ int insert(uint32_t id) const {
         uint32_t w0, tag;
         locate(id, w0, tag);
@@ -424,11 +430,10 @@ struct TagSet {
             const uint4 v = *reinterpret_cast<const uint4*>(tab + w0);
             if (present(v, tag)) return 0;
             const uint32_t u = used(v);
-            if (u == 8) return Visited::probe<false, false>(sec, smask, (id * MUL) >> sshift, id) == 1 ? 2 : 0;
             uint32_t widx, expect, desired;
-            slot_of(v, u, tag, widx, expect, desired);
-            if (atomicCAS(&tab[w0 + widx], expect, desired) == expect) return 1;
-            // the word changed under us (another lane filled this or the neighbouring entry): look again
+            slot_of(v, entry_for(u, tag), tag, widx, expect, desired);
+            if (atomicCAS(&tab[w0 + widx], expect, desired) == expect) return u < 8u ? 1 : 2;
+            // the word changed under us (another lane wrote this or the neighbouring entry): look again
         }
     }
 };

@@ -310,8 +310,12 @@ uint32_t vdb_index::pick_hash_log2(size_t, bool& global) const {
 void vdb_index::run_search(SearchArgs a, size_t nq, hipStream_t s, bool retry_on_overflow, const float* d_q_all) {
     bool global = false;
     a.hash_log2 = pick_hash_log2(a.ef, global);
+    // 16-bit visited table of the register-resident beam: 4096 entries (8 KiB of LDS, twelve wavefronts per CU);
+    // the id-to-tag mapping needs slots below 2^(tag_log2 + 12), so very large shards take a larger table
     const char* te = getenv("VDB_TAG_LOG2"); const int forced_tags = te ? atoi(te) : 0;
-    a.tag_log2 = (forced_tags >= 11 && forced_tags <= 15) ? (uint32_t)forced_tags : 13;
+    a.tag_log2 = 12;
+    while (a.tag_log2 < 15 && ((uint64_t)a.g.n >> (a.tag_log2 + 12)) != 0) ++a.tag_log2;
+    if (forced_tags >= 11 && forced_tags <= 15) a.tag_log2 = (uint32_t)forced_tags;
     // one spill table per possibly resident wavefront (256 CUs x 16), 2^15 ids each
     a.spill_log2 = 15;
     a.spill_tables = 4096;
@@ -341,13 +345,8 @@ void vdb_index::run_search(SearchArgs a, size_t nq, hipStream_t s, bool retry_on
         launch_search(b, s);
     } else
     launch_search(a, s);
-    if (reg_list_chunks(a) > 0) {
-        // The register-resident beam keeps its visited set in LDS alone and flags a query that fills
-        // it.  A follow-up launch of the LDS-list kernel with its HBM spill tables, on the same
-        // stream, takes only the flagged queries (every other block leaves at once).
-        SearchArgs c = a; c.only_flagged = 1; c.force_generic = 1;
-        launch_search(c, s);
-    }
+    // the register-resident beam never overflows (its visited set forgets instead): nothing to follow up
+    if (reg_list_chunks(a) > 0) return;
     if (!retry_on_overflow) return;
     std::vector<vdb_query_stats> st(nq);
     VDB_HIP(hipMemcpyAsync(st.data(), a.stats, nq * sizeof(vdb_query_stats), hipMemcpyDeviceToHost, s));

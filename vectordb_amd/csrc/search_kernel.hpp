@@ -26,8 +26,7 @@ struct Searcher {
     static constexpr int NCC = NC > 0 ? NC : 1;
     static constexpr int CAND_CAP = NC > 0 ? 256 : WAVE;   // candidate staging (cand / craw) entries
     uint2* perm = nullptr;                         // NC * 64 {key, slot} pairs: staging area of the register-resident list
-    static constexpr uint32_t SEC_IDS = 512, SEC_LIMIT = 320;   // secondary visited table of the register-resident beam
-    TagSet tags; uint32_t tag_limit = 0;
+    TagSet tags;
     const SearchArgs& a;
     const GraphView& gv;
     float* qlds; uint32_t* cand; float* craw;
@@ -407,25 +406,23 @@ struct Searcher {
         const float INF = __int_as_float(0x7f800000);
         const bool full = gv.stride == (uint32_t)(GG * CC * 4);
         uint32_t* const par_lds = reinterpret_cast<uint32_t*>(craw);     // parents pass through the head of craw
-        const uint32_t vlimit = tag_limit;
         const TagSet ts = tags;
         const uint32_t* const adj0 = gv.adj0;
         float rk[NCC]; uint32_t rv[NCC];
 #pragma unroll
         for (int c = 0; c < NCC; ++c) { rk[c] = INF; rv[c] = FLAG_EXPANDED; }
         const uint32_t cap = ef;
-        uint32_t n = 0, vcount = 0, scount = 0;
+        uint32_t n = 0;
+        bool forgot = false;             // the visited set replaced an id: candidates are checked against the list from here on
         float worst = INF;
         {   // clear the visited set
             const uint32_t words = (ts.idmask >> 15) * 4 + 4;
             for (uint32_t i = lane * 4; i < words; i += WAVE * 4) *reinterpret_cast<uint4*>(ts.tab + i) = make_uint4(0u, 0u, 0u, 0u);
-            for (uint32_t i = lane * 4; i < SEC_IDS; i += WAVE * 4) *reinterpret_cast<uint4*>(ts.sec + i) = make_uint4(HASH_EMPTY, HASH_EMPTY, HASH_EMPTY, HASH_EMPTY);
             wave_sync();
         }
         uint32_t start = entry;
         if (is_deleted(entry) && a.fallback_live != NONE32) start = a.fallback_live;      // hnsw.rs:440-444
         if (lane == 0) { cand[0] = start; ts.insert(start); }
-        vcount = 1;
         wave_sync();
         if (full) score_rows<true>(1); else score_rows<false>(1);
         rows_scored += 1;
@@ -471,13 +468,12 @@ struct Searcher {
             // ---- round 0: the inline neighbours (block words 1..62) of all parents at once; further
             // rounds: one overflow chunk of a high-degree parent each ----
             uint32_t hub_e = 0, hub_ch = 1, hub_left = 0;     // overflow chunks of high-degree parents still to visit
-            bool room = true;
             for (uint32_t round = 0; ; ++round) {
                 int m = 0;
                 if (round == 0) {
                     uint32_t nb[EMAX], w0[EMAX], tag[EMAX], widx[EMAX], expect[EMAX], desired[EMAX], old[EMAX], half[EMAX];
                     uint4 bk[EMAX];
-                    bool tr[EMAX], fresh[EMAX], slow[EMAX];
+                    bool tr[EMAX], fresh[EMAX], slow[EMAX], full_b[EMAX];
 #pragma unroll
                     for (int e = 0; e < EMAX; ++e) {
                         nb[e] = w[e];
@@ -494,11 +490,11 @@ struct Searcher {
                         if (gv.deleted) want = want && !bit_test(gv.deleted, nb[e]);      // hnsw.rs:475
                         const bool pres = TagSet::present(bk[e], tag[e]);
                         const uint32_t u = TagSet::used(bk[e]);
-                        const bool absent = want & !pres;
-                        tr[e] = absent & (u < 8);
-                        slow[e] = absent & (u == 8);                                      // full bucket: generic insert
-                        TagSet::slot_of(bk[e], u, tag[e], widx[e], expect[e], desired[e]);
-                        half[e] = (u & 1u) * 16u;
+                        tr[e] = want & !pres;
+                        full_b[e] = tr[e] & (u == 8);                                     // full bucket: one of its ids is forgotten
+                        const uint32_t en = TagSet::entry_for(u, tag[e]);
+                        TagSet::slot_of(bk[e], en, tag[e], widx[e], expect[e], desired[e]);
+                        half[e] = (en & 1u) * 16u;
                     }
 #ifdef VDB_TIMING
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -517,18 +513,18 @@ struct Searcher {
                         // the word changed under us: if our entry now holds our tag, another lane carried the
                         // same id (a neighbour shared by two parents) and it counts as visited
                         const bool same = ((old[e] >> half[e]) & 0xFFFFu) == tag[e];
-                        slow[e] = slow[e] | (tr[e] & (old[e] != expect[e]) & !same);
-                        any_slow = any_slow | slow[e];
+                        slow[e] = tr[e] & (old[e] != expect[e]) & !same;
+                        any_slow = any_slow | slow[e] | full_b[e];
                     }
                     if (ballot(any_slow)) {
 #pragma unroll
                         for (int e = 0; e < EMAX; ++e) {
+                            int r = 0;
                             if (ballot(slow[e])) {
-                                int r = 0;
                                 if (slow[e]) r = ts.insert(nb[e]);
                                 if (slow[e]) fresh[e] = r != 0;
-                                scount += popc64(ballot(r == 2));
                             }
+                            forgot = forgot | (ballot(full_b[e] | (r == 2)) != 0);
                         }
                     }
                     VDB_T_MARK(8);
@@ -557,14 +553,14 @@ struct Searcher {
                     int r = 0;
                     if (fresh) r = ts.insert(nb);
                     fresh = r != 0;
-                    scount += popc64(ballot(r == 2));
+                    forgot = forgot | (ballot(r == 2) != 0);
                     const uint64_t mk = ballot(fresh);
                     if (fresh) cand[rank_below(mk)] = nb;
                     m = popc64(mk);
                 }
                 VDB_T_MARK(2);
                 if (m == 0) continue;
-                vcount += m; rows_scored += m;
+                rows_scored += m;
                 wave_sync();
                 if (full) score_rows<true>(m); else score_rows<false>(m);
                 VDB_T_MARK(3);
@@ -584,9 +580,30 @@ struct Searcher {
                     float kj = kjr[0]; uint32_t sj = sjr[0];
 #pragma unroll
                     for (int r = 1; r < CAND_CAP / WAVE; ++r) if (base == r * WAVE) { kj = kjr[r]; sj = sjr[r]; }
-                    const bool pass = have && (n < cap || kj < worst);            // hnsw.rs:486
-                    const uint64_t pm = ballot(pass);
+                    bool pass = have && (n < cap || kj < worst);                  // hnsw.rs:486
+                    uint64_t pm = ballot(pass);
                     if (pm == 0) continue;
+                    if (forgot) {
+                        // a candidate the visited set had forgotten may already be in the list: same key, same id
+                        uint64_t dup = 0, it = pm;
+                        while (it) {
+                            const int l = __ffsll((unsigned long long)it) - 1; it &= it - 1;
+                            const float k = readlane_f(kj, l);
+                            uint64_t eq = 0;
+#pragma unroll
+                            for (int c = 0; c < NCC; ++c) eq |= ballot(rk[c] == k);
+                            if (eq) {
+                                const uint32_t s = readlane_u(sj, l);
+                                uint64_t hit = 0;
+#pragma unroll
+                                for (int c = 0; c < NCC; ++c) hit |= ballot(rk[c] == k && (rv[c] & ~FLAG_EXPANDED) == s);
+                                if (hit) dup |= 1ull << l;
+                            }
+                        }
+                        pm &= ~dup;
+                        pass = pass && !((dup >> lane) & 1ull);
+                        if (pm == 0) continue;
+                    }
                     if (!pass) kj = INF;
                     const uint32_t mp = popc64(pm);
                     uint32_t sh[NCC], mypos = 0;
@@ -625,9 +642,7 @@ struct Searcher {
                     worst = (n >= cap) ? readlane_f(rk[NCC - 1], (int)((cap - 1) & 63u)) : INF;
                 }
                 VDB_T_MARK(4);
-                if (vcount > vlimit || scount > SEC_LIMIT) { room = false; break; }
             }
-            if (!room) { flags |= QF_HASH_OVERFLOW; break; }
         }
         // hand the list over in LDS (Euclidean: root of the squared keys)
 #pragma unroll
@@ -756,7 +771,6 @@ struct Searcher {
             craw = reinterpret_cast<float*>(smem + CAND_CAP * 4);
             off = (area + 15) & ~(size_t)15;
             tags.tab = reinterpret_cast<uint32_t*>(smem + off); off += (size_t)2 << a.tag_log2;
-            tags.sec = reinterpret_cast<uint32_t*>(smem + off); off += SEC_IDS * 4;
         } else {
             R.key = reinterpret_cast<float*>(smem + off); off += ef_cap * 4;
             R.val = reinterpret_cast<uint32_t*>(smem + off); off += ef_cap * 4;
@@ -771,16 +785,12 @@ struct Searcher {
             if (NC > 0) {
                 perm = reinterpret_cast<uint2*>(smem + off); off += (size_t)NCC * WAVE * 8;
                 tags.tab = reinterpret_cast<uint32_t*>(smem + off); off += (size_t)2 << a.tag_log2;
-                tags.sec = reinterpret_cast<uint32_t*>(smem + off); off += SEC_IDS * 4;
             }
             cand = reinterpret_cast<uint32_t*>(smem + off); off += CAND_CAP * 4;
             craw = reinterpret_cast<float*>(smem + off); off += CAND_CAP * 4;
             qlds = reinterpret_cast<float*>(smem + off); off += (size_t)gv.stride * 4;
         }
-        if (NC > 0) {
-            tags.idmask = (1u << (a.tag_log2 + 12)) - 1; tags.smask = SEC_IDS / 4 - 1; tags.sshift = 25;
-            tag_limit = (7u << a.tag_log2) / 10 - 4 * WAVE;                  // room for one more step
-        }
+        if (NC > 0) tags.idmask = (1u << (a.tag_log2 + 12)) - 1;
         vis.mask = (1u << (a.hash_log2 - 2)) - 1; vis.shift = 32 - (a.hash_log2 - 2);
         vis.limit = (1u << a.hash_log2) - (1u << a.hash_log2) / 4 - (NC > 0 ? 4 * WAVE : WAVE);   // room for one more step
         vis.tab = reinterpret_cast<uint32_t*>(smem + off);
@@ -884,7 +894,7 @@ __global__ void __launch_bounds__(64) search_kernel(SearchArgs a) {
 template <int MODE, int METRIC, int NC>
 void launch_search_shape(const SearchArgs& a, size_t lds, hipStream_t st) {
     const uint32_t chunks = a.g.stride / 4;
-    constexpr int P8 = NC > 0 ? 3 : 4;             // row groups in flight per lane for short rows
+    constexpr int P8 = NC > 0 ? 2 : 4;             // row groups in flight per lane for short rows
     if (chunks <= 32) hipLaunchKernelGGL((search_kernel<MODE, 8, 4, P8, false, METRIC, NC>), dim3(a.nq), dim3(64), lds, st, a);
     else if (chunks <= 256) hipLaunchKernelGGL((search_kernel<MODE, 64, 4, 8, false, METRIC, NC>), dim3(a.nq), dim3(64), lds, st, a);
     else if (chunks <= 512) hipLaunchKernelGGL((search_kernel<MODE, 64, 8, 4, false, METRIC, NC>), dim3(a.nq), dim3(64), lds, st, a);
