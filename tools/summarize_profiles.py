@@ -3,14 +3,17 @@ summaries under profiles/: kernel stats, per-dispatch table of the timed kernel,
 import glob, json, os, sys
 import pandas as pd
 
+def newest(pattern):          # earlier collections may still lie in the same directory
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 bench = json.loads(open(f"{src}/trace.json").read().strip().splitlines()[-1])
 ef = bench["config"]["ef_search"]
-stats = pd.read_csv(glob.glob(f"{src}/trace/*/*_kernel_stats.csv")[0])
+stats = pd.read_csv(newest(f"{src}/trace/*/*_kernel_stats.csv"))
 stats.to_csv(f"profiles/{tag}_bench_ef{ef}_kernel_stats.csv", index=False)
-tr = pd.read_csv(glob.glob(f"{src}/trace/*/*_kernel_trace.csv")[0])
+tr = pd.read_csv(newest(f"{src}/trace/*/*_kernel_trace.csv"))
 sk = tr[tr.Kernel_Name.str.contains(r"search_kernel<0")].copy()
 sk["Duration_us"] = (sk.End_Timestamp - sk.Start_Timestamp) / 1e3
 main_name = sk.groupby("Kernel_Name").Duration_us.sum().idxmax()
@@ -19,7 +22,7 @@ cols = ["Kernel_Name", "Duration_us", "Grid_Size_X", "Workgroup_Size_X", "LDS_Bl
 sk[[c for c in cols if c in sk.columns]].tail(3 * bench["steps"]).to_csv(f"profiles/{tag}_bench_ef{ef}_search_kernel_dispatches.csv", index=False)
 
 def pmc(which):
-    df = pd.read_csv(glob.glob(f"{src}/{which}/*/*_counter_collection.csv")[0])
+    df = pd.read_csv(newest(f"{src}/{which}/*/*_counter_collection.csv"))
     k = df[df.Kernel_Name == main_name]
     last = sorted(k.Dispatch_Id.unique())[-5:]
     return float(k[k.Dispatch_Id.isin(last)].groupby("Dispatch_Id").Counter_Value.sum().mean()), len(last)

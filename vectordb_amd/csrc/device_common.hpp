@@ -386,39 +386,37 @@ struct Visited {
 
 // Visited set of the register-resident beam, 16 bits per id.  An id below 2^(bbits + 15) is mapped
 // one-to-one (odd multiplier modulo a power of two) onto a bucket number (bbits) and a 15-bit tag, so
-// "present" is never wrong; a bucket is 16 bytes = eight tags (bit 15 marks a used entry), filled
-// front to back, and one ds_read_b128 shows whether the id is present and where the first free entry
-// is.  An id that meets a full bucket replaces one of its eight tags: the set may FORGET an id, never
+// "present" is never wrong; a bucket is 8 bytes = four tags (bit 15 marks a used entry), filled front
+// to back, and one ds_read_b64 shows whether the id is present and where the first free entry is.
+// An id that meets a full bucket replaces one of its four tags: the set may FORGET an id, never
 // invent one.  A forgotten id that turns up again is scored again and then either fails the
 // admission test it failed before (the bound only tightens) or is found in the result list by its
 // key and id (the merge drops it), so results do not depend on what was forgotten — only the work does.
 struct TagSet {
     uint32_t* tab; uint32_t idmask;
-    static constexpr uint32_t MUL = 2654435761u, USED = 0x80008000u;
+    static constexpr uint32_t MUL = 2654435761u, USED = 0x80008000u, WAYS = 4;
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     static __device__ __forceinline__ uint32_t pkmin(uint32_t a, uint32_t b) {
         return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
     }
     __device__ __forceinline__ void locate(uint32_t id, uint32_t& word0, uint32_t& tag) const {
         const uint32_t h = (id * MUL) & idmask;
-        word0 = (h >> 15) << 2; tag = (h & 0x7FFFu) | 0x8000u;
+        word0 = (h >> 15) << 1; tag = (h & 0x7FFFu) | 0x8000u;
     }
-    static __device__ __forceinline__ bool present(const uint4 v, uint32_t tag) {
+    static __device__ __forceinline__ bool present(const uint2 v, uint32_t tag) {
         const uint32_t t2 = tag | (tag << 16);
-        uint32_t m = pkmin(pkmin(v.x ^ t2, v.y ^ t2), pkmin(v.z ^ t2, v.w ^ t2));
+        uint32_t m = pkmin(v.x ^ t2, v.y ^ t2);
         m = pkmin(m, __builtin_amdgcn_alignbit(m, m, 16));
         return (m & 0xFFFFu) == 0;
     }
-    static __device__ __forceinline__ uint32_t used(const uint4 v) {
-        return __popc(v.x & USED) + __popc(v.y & USED) + __popc(v.z & USED) + __popc(v.w & USED);
-    }
+    static __device__ __forceinline__ uint32_t used(const uint2 v) { return __popc(v.x & USED) + __popc(v.y & USED); }
     // Entry that takes `tag` in a bucket with u used entries: the first free one, or, in a full
-    // bucket, the entry three bits of the tag pick (its id is forgotten).
-    static __device__ __forceinline__ uint32_t entry_for(uint32_t u, uint32_t tag) { return u < 8u ? u : ((tag >> 5) & 7u); }
-    // CAS operands that put `tag` into entry e (< 8) of bucket v
-    static __device__ __forceinline__ void slot_of(const uint4 v, uint32_t e, uint32_t tag, uint32_t& widx, uint32_t& expect, uint32_t& desired) {
+    // bucket, the entry two bits of the tag pick (its id is forgotten).
+    static __device__ __forceinline__ uint32_t entry_for(uint32_t u, uint32_t tag) { return u < WAYS ? u : ((tag >> 5) & (WAYS - 1u)); }
+    // CAS operands that put `tag` into entry e (< 4) of bucket v
+    static __device__ __forceinline__ void slot_of(const uint2 v, uint32_t e, uint32_t tag, uint32_t& widx, uint32_t& expect, uint32_t& desired) {
         widx = e >> 1;
-        expect = widx == 0 ? v.x : widx == 1 ? v.y : widx == 2 ? v.z : v.w;
+        expect = widx == 0 ? v.x : v.y;
         const uint32_t sh = (e & 1u) * 16u;
         desired = (expect & ~(0xFFFFu << sh)) | (tag << sh);
     }
@@ -427,12 +425,12 @@ struct TagSet {
         uint32_t w0, tag;
         locate(id, w0, tag);
         for (;;) {
-            const uint4 v = *reinterpret_cast<const uint4*>(tab + w0);
+            const uint2 v = *reinterpret_cast<const uint2*>(tab + w0);
             if (present(v, tag)) return 0;
             const uint32_t u = used(v);
             uint32_t widx, expect, desired;
             slot_of(v, entry_for(u, tag), tag, widx, expect, desired);
-            if (atomicCAS(&tab[w0 + widx], expect, desired) == expect) return u < 8u ? 1 : 2;
+            if (atomicCAS(&tab[w0 + widx], expect, desired) == expect) return u < WAYS ? 1 : 2;
             // the word changed under us (another lane wrote this or the neighbouring entry): look again
         }
     }

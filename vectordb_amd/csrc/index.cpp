@@ -311,11 +311,11 @@ void vdb_index::run_search(SearchArgs a, size_t nq, hipStream_t s, bool retry_on
     bool global = false;
     a.hash_log2 = pick_hash_log2(a.ef, global);
     // 16-bit visited table of the register-resident beam: 4096 entries (8 KiB of LDS, twelve wavefronts per CU);
-    // the id-to-tag mapping needs slots below 2^(tag_log2 + 12), so very large shards take a larger table
+    // the id-to-tag mapping needs slots below 2^(tag_log2 + 13), so very large shards take a larger table
     const char* te = getenv("VDB_TAG_LOG2"); const int forced_tags = te ? atoi(te) : 0;
     a.tag_log2 = 12;
-    while (a.tag_log2 < 15 && ((uint64_t)a.g.n >> (a.tag_log2 + 12)) != 0) ++a.tag_log2;
-    if (forced_tags >= 11 && forced_tags <= 15) a.tag_log2 = (uint32_t)forced_tags;
+    while (a.tag_log2 < 15 && ((uint64_t)a.g.n >> (a.tag_log2 + 13)) != 0) ++a.tag_log2;
+    if (forced_tags >= 7 && forced_tags <= 15) a.tag_log2 = (uint32_t)forced_tags;      // tests shrink it to force forgetting
     // one spill table per possibly resident wavefront (256 CUs x 16), 2^15 ids each
     a.spill_log2 = 15;
     a.spill_tables = 4096;
@@ -328,22 +328,6 @@ void vdb_index::run_search(SearchArgs a, size_t nq, hipStream_t s, bool retry_on
         VDB_HIP(hipStreamSynchronize(s));
     }
     a.spill_locks = s_spill.p; a.spill_pool = s_spill.p + a.spill_tables;
-    // Opt-in (VDB_SPLIT_DESCENT=1): the upper-layer descent as a launch of its own (a few hundred bytes
-    // of LDS per wavefront, so 28 are resident per CU), then the beam from the stored entries.  With
-    // batches on two streams the descent of one overlaps the beam of the other (+4 % at 1M x 128,
-    // 10k queries); a single stream gains nothing because the descent launch is bound by its own
-    // longest walks, so the default keeps one launch.
-    const char* se = getenv("VDB_SPLIT_DESCENT");
-    const bool split = reg_list_chunks(a) > 0 && a.mode == MODE_SEARCH && a.g.ublk && a.max_level >= 1 && !a.q_entry && a.stats &&
-                       se && atoi(se) != 0;
-    if (split) {
-        auto& eb = s_entry_by_stream[s];
-        eb.reserve(nq, s, false);
-        SearchArgs d = a; d.mode = MODE_DESCEND; d.entry_out = eb.p;
-        launch_search(d, s);
-        SearchArgs b = a; b.q_entry = eb.p;
-        launch_search(b, s);
-    } else
     launch_search(a, s);
     // the register-resident beam never overflows (its visited set forgets instead): nothing to follow up
     if (reg_list_chunks(a) > 0) return;

@@ -79,7 +79,6 @@ struct vdb_index {
     mutable vdb::DevBuf<float> s_q, s_raw, s_sub_vecs; mutable vdb::DevBuf<uint64_t> s_sub_ids; mutable vdb::DevBuf<vdb_scored_point> s_out, s_knn, s_cand;
     mutable vdb::DevBuf<uint32_t> s_knn_words, s_n, s_slots, s_lvl, s_off, s_nb, s_nbc, s_hash, s_spill; mutable vdb::DevBuf<vdb_query_stats> s_stats;
     mutable std::map<hipStream_t, vdb::DevBuf<vdb_query_stats>> s_stats_by_stream;
-    mutable std::map<hipStream_t, vdb::DevBuf<uint32_t>> s_entry_by_stream;     // layer-0 entries between the two search launches
 
     vdb_index(vdb_metric metric, size_t m, size_t ef, size_t cap, size_t dim, const vdb_options& o);
     ~vdb_index();

@@ -11,13 +11,11 @@ void launch_search_plain(const SearchArgs& a, size_t lds, hipStream_t st);
 void launch_search_build(const SearchArgs& a, size_t lds, hipStream_t st);
 void launch_search_masked(const SearchArgs& a, size_t lds, hipStream_t st);
 void launch_search_literal(const SearchArgs& a, size_t lds, hipStream_t st);
-void launch_search_descend(const SearchArgs& a, size_t lds, hipStream_t st);
 
 size_t search_lds_bytes(const SearchArgs& a) {
     const size_t ef_cap = (a.ef + 63u) & ~63u;
     const size_t nc = reg_list_chunks(a), hash = (size_t)4 << a.hash_log2, row = (size_t)a.g.stride * 4;
     const size_t staging = (nc ? 256 : 64) * 8;      // cand + craw
-    if (a.mode == MODE_DESCEND) return staging + row;
     const size_t tags = nc ? ((size_t)2 << a.tag_log2) : 0;   // 16-bit visited table
     if (nc && a.mode == MODE_SEARCH) return ((std::max(std::max(nc * 512, row), staging) + 15) & ~(size_t)15) + tags;   // one shared staging area
     return ef_cap * 16 + (a.mode == MODE_MASKED ? ef_cap * 16 : 0) + nc * 512 + tags + staging + row + hash;
@@ -31,7 +29,6 @@ void launch_search(const SearchArgs& a, hipStream_t st) {
         case MODE_BUILD: launch_search_build(a, lds, st); break;
         case MODE_MASKED: launch_search_masked(a, lds, st); break;
         case MODE_LITERAL: launch_search_literal(a, lds, st); break;
-        case MODE_DESCEND: launch_search_descend(a, lds, st); break;
         default: launch_search_plain(a, lds, st); break;
     }
     VDB_HIP(hipGetLastError());

@@ -35,8 +35,7 @@ struct GraphView {
     int metric;
 };
 
-// MODE_DESCEND runs only the upper-layer descent of MODE_SEARCH and stores each query's layer-0 entry.
-enum SearchMode : int { MODE_SEARCH = 0, MODE_BUILD = 1, MODE_MASKED = 2, MODE_LITERAL = 3, MODE_DESCEND = 4 };
+enum SearchMode : int { MODE_SEARCH = 0, MODE_BUILD = 1, MODE_MASKED = 2, MODE_LITERAL = 3 };
 
 struct SearchArgs {
     GraphView g;
@@ -54,7 +53,7 @@ struct SearchArgs {
     uint32_t* out_n;             // nq
     vdb_query_stats* stats;      // nq or nullptr
     uint32_t hash_log2;          // LDS visited table capacity = 1 << hash_log2 ids
-    uint32_t tag_log2;           // register-resident beam: 16-bit visited table of 1 << tag_log2 entries (slots below 2^(tag_log2 + 12))
+    uint32_t tag_log2;           // register-resident beam: 16-bit visited table of 1 << tag_log2 entries (slots below 2^(tag_log2 + 13))
     uint32_t* spill_pool;        // spill tables in HBM for queries that outgrow the LDS table
     uint32_t* spill_locks;       // one word per spill table: 0 free, 1 taken (zeroed before the launch)
     uint32_t spill_tables, spill_log2;
@@ -67,9 +66,7 @@ struct SearchArgs {
     // MODE_MASKED / MODE_LITERAL
     const uint32_t* pass_bits;   // filter passes (errors count as false)
     const uint32_t* err_bits;    // evaluate_filter returned Err
-    const uint32_t* q_entry;     // MODE_LITERAL: per-query entry (nullptr: args.entry); MODE_SEARCH: layer-0 entries of an
-                                 // earlier MODE_DESCEND launch (its counters in `stats` are carried on)
-    uint32_t* entry_out;         // MODE_DESCEND: nq layer-0 entries
+    const uint32_t* q_entry;     // MODE_LITERAL: per-query entry (nullptr: args.entry)
     vdb_scored_point* cand_scratch;   // MODE_LITERAL: nq x cand_cap candidate queue
     uint32_t cand_cap;
 };
@@ -80,7 +77,7 @@ enum : uint32_t { QF_HASH_OVERFLOW = 1u, QF_FILTER_ERROR = 2u, QF_CAND_OVERFLOW 
 // 64-entry chunks of the register-resident layer-0 result list (FAST arithmetic, unfiltered search
 // and graph construction, ef up to 256); 0 = the list lives in LDS.
 inline uint32_t reg_list_chunks(const SearchArgs& a) {
-    if (a.force_generic || ((uint64_t)a.g.n >> (a.tag_log2 + 12)) != 0 || a.arith != VDB_ARITH_FAST || (a.mode != MODE_SEARCH && a.mode != MODE_BUILD) || a.ef == 0 || a.ef > 256) return 0;
+    if (a.force_generic || ((uint64_t)a.g.n >> (a.tag_log2 + 13)) != 0 || a.arith != VDB_ARITH_FAST || (a.mode != MODE_SEARCH && a.mode != MODE_BUILD) || a.ef == 0 || a.ef > 256) return 0;
     return (a.ef + 63u) / 64u;
 }
 

@@ -416,7 +416,7 @@ struct Searcher {
         bool forgot = false;             // the visited set replaced an id: candidates are checked against the list from here on
         float worst = INF;
         {   // clear the visited set
-            const uint32_t words = (ts.idmask >> 15) * 4 + 4;
+            const uint32_t words = (ts.idmask >> 15) * 2 + 2;
             for (uint32_t i = lane * 4; i < words; i += WAVE * 4) *reinterpret_cast<uint4*>(ts.tab + i) = make_uint4(0u, 0u, 0u, 0u);
             wave_sync();
         }
@@ -472,13 +472,13 @@ struct Searcher {
                 int m = 0;
                 if (round == 0) {
                     uint32_t nb[EMAX], w0[EMAX], tag[EMAX], widx[EMAX], expect[EMAX], desired[EMAX], old[EMAX], half[EMAX];
-                    uint4 bk[EMAX];
+                    uint2 bk[EMAX];
                     bool tr[EMAX], fresh[EMAX], slow[EMAX], full_b[EMAX];
 #pragma unroll
                     for (int e = 0; e < EMAX; ++e) {
                         nb[e] = w[e];
                         ts.locate(nb[e], w0[e], tag[e]);
-                        bk[e] = *reinterpret_cast<const uint4*>(ts.tab + w0[e]);
+                        bk[e] = *reinterpret_cast<const uint2*>(ts.tab + w0[e]);
                     }
 #pragma unroll
                     for (int e = 0; e < EMAX; ++e) {
@@ -491,7 +491,7 @@ struct Searcher {
                         const bool pres = TagSet::present(bk[e], tag[e]);
                         const uint32_t u = TagSet::used(bk[e]);
                         tr[e] = want & !pres;
-                        full_b[e] = tr[e] & (u == 8);                                     // full bucket: one of its ids is forgotten
+                        full_b[e] = tr[e] & (u == TagSet::WAYS);                          // full bucket: one of its ids is forgotten
                         const uint32_t en = TagSet::entry_for(u, tag[e]);
                         TagSet::slot_of(bk[e], en, tag[e], widx[e], expect[e], desired[e]);
                         half[e] = (en & 1u) * 16u;
@@ -584,17 +584,20 @@ struct Searcher {
                     uint64_t pm = ballot(pass);
                     if (pm == 0) continue;
                     if (forgot) {
-                        // a candidate the visited set had forgotten may already be in the list: same key, same id
+                        // a candidate the visited set had forgotten may already be in the list (same key, same id),
+                        // or sit twice among the candidates: an id inserted by one lane can be replaced before
+                        // the lane that carries it for another parent looks it up
                         uint64_t dup = 0, it = pm;
                         while (it) {
                             const int l = __ffsll((unsigned long long)it) - 1; it &= it - 1;
                             const float k = readlane_f(kj, l);
-                            uint64_t eq = 0;
+                            const uint64_t before = pm & ((1ull << l) - 1ull);
+                            uint64_t eq = ballot(kj == k) & before;               // equal keys are rare: ids are compared only then
 #pragma unroll
                             for (int c = 0; c < NCC; ++c) eq |= ballot(rk[c] == k);
                             if (eq) {
                                 const uint32_t s = readlane_u(sj, l);
-                                uint64_t hit = 0;
+                                uint64_t hit = ballot(kj == k && sj == s) & before;
 #pragma unroll
                                 for (int c = 0; c < NCC; ++c) hit |= ballot(rk[c] == k && (rv[c] & ~FLAG_EXPANDED) == s);
                                 if (hit) dup |= 1ull << l;
@@ -752,11 +755,7 @@ struct Searcher {
         // ---- carve LDS (every offset a multiple of 16 bytes) ----
         const uint32_t ef_cap = (a.ef + 63u) & ~63u;
         size_t off = 0;
-        if (MODE == MODE_DESCEND) {
-            cand = reinterpret_cast<uint32_t*>(smem); craw = reinterpret_cast<float*>(smem + CAND_CAP * 4);
-            qlds = reinterpret_cast<float*>(smem + CAND_CAP * 8);
-            off = (size_t)CAND_CAP * 8 + (size_t)gv.stride * 4;
-        } else if (NC > 0 && MODE == MODE_SEARCH) {
+        if (NC > 0 && MODE == MODE_SEARCH) {
             // register-resident list: LDS only stages permutations, the query (until it is in
             // registers) and the final list, all in one area
             // (candidate ids + scores, then the permutation of the merge, which has read them into registers)
@@ -790,7 +789,7 @@ struct Searcher {
             craw = reinterpret_cast<float*>(smem + off); off += CAND_CAP * 4;
             qlds = reinterpret_cast<float*>(smem + off); off += (size_t)gv.stride * 4;
         }
-        if (NC > 0) tags.idmask = (1u << (a.tag_log2 + 12)) - 1;
+        if (NC > 0) tags.idmask = (1u << (a.tag_log2 + 13)) - 1;
         vis.mask = (1u << (a.hash_log2 - 2)) - 1; vis.shift = 32 - (a.hash_log2 - 2);
         vis.limit = (1u << a.hash_log2) - (1u << a.hash_log2) / 4 - (NC > 0 ? 4 * WAVE : WAVE);   // room for one more step
         vis.tab = reinterpret_cast<uint32_t*>(smem + off);
@@ -842,17 +841,9 @@ struct Searcher {
                 wave_sync();
             }
             if (a.out && !(flags & QF_HASH_OVERFLOW)) emit(q, R, false);                // layer-0 beam, full list
-        } else if (MODE == MODE_DESCEND) {
-            uint32_t cur = a.entry;
-            uint32_t ref = make_uref(gv.upper_base[cur], gv.upper_cnt[cur]); float kc = 0.f; bool hc = false;
-            for (uint32_t l = a.max_level; l >= 1; --l) cur = greedy_fused(cur, ref, l, kc, hc);
-            if (lane == 0) a.entry_out[q] = cur;
         } else {
             uint32_t cur = a.entry;
-            if (MODE == MODE_SEARCH && a.q_entry) {                         // descent done by an earlier launch
-                cur = a.q_entry[q];
-                if (a.stats) { rows_scored = a.stats[q].rows_scored; expanded = a.stats[q].expanded; adj_entries = a.stats[q].adj_entries; }
-            } else if (gv.ublk) {
+            if (gv.ublk) {
                 uint32_t ref = make_uref(gv.upper_base[cur], gv.upper_cnt[cur]); float kc = 0.f; bool hc = false;
                 for (uint32_t l = a.max_level; l >= 1; --l) cur = greedy_fused(cur, ref, l, kc, hc);
             } else
@@ -870,7 +861,7 @@ struct Searcher {
 #ifdef VDB_TIMING
         // diagnostic build only: adj_entries carries the wavefront's lifetime in 10 ns ticks, rows_scored its start tick
         adj_entries = (uint32_t)(wall_clock64() - t_begin); rows_scored = (uint32_t)t_begin;
-        if (lane == 0 && a.out && a.top_k >= 5 && MODE != MODE_DESCEND) {      // phase totals overwrite this query's result records
+        if (lane == 0 && a.out && a.top_k >= 5) {      // phase totals overwrite this query's result records
             unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.out + (size_t)q * a.top_k);
             tacc[9] -= t_begin; tacc[5] = wall_clock64() - t_begin;
             for (int i = 0; i < 10; ++i) dbg[i] = tacc[i];
@@ -895,9 +886,10 @@ template <int MODE, int METRIC, int NC>
 void launch_search_shape(const SearchArgs& a, size_t lds, hipStream_t st) {
     const uint32_t chunks = a.g.stride / 4;
     constexpr int P8 = NC > 0 ? 2 : 4;             // row groups in flight per lane for short rows
+    constexpr int P64 = NC > 0 ? 4 : 8;            // rows in flight per wave for long rows (x 2 chunks: half of it)
     if (chunks <= 32) hipLaunchKernelGGL((search_kernel<MODE, 8, 4, P8, false, METRIC, NC>), dim3(a.nq), dim3(64), lds, st, a);
-    else if (chunks <= 256) hipLaunchKernelGGL((search_kernel<MODE, 64, 4, 8, false, METRIC, NC>), dim3(a.nq), dim3(64), lds, st, a);
-    else if (chunks <= 512) hipLaunchKernelGGL((search_kernel<MODE, 64, 8, 4, false, METRIC, NC>), dim3(a.nq), dim3(64), lds, st, a);
+    else if (chunks <= 256) hipLaunchKernelGGL((search_kernel<MODE, 64, 4, P64, false, METRIC, NC>), dim3(a.nq), dim3(64), lds, st, a);
+    else if (chunks <= 512) hipLaunchKernelGGL((search_kernel<MODE, 64, 8, P64 / 2, false, METRIC, NC>), dim3(a.nq), dim3(64), lds, st, a);
     else throw Failure(err_arg("dimension above 2048 is not supported"));
 }
 template <int MODE, int METRIC>
