@@ -310,7 +310,7 @@ uint32_t vdb_index::pick_hash_log2(size_t, bool& global) const {
 void vdb_index::run_search(SearchArgs a, size_t nq, hipStream_t s, bool retry_on_overflow, const float* d_q_all) {
     bool global = false;
     a.hash_log2 = pick_hash_log2(a.ef, global);
-    // 16-bit visited table of the register-resident beam: 4096 entries (8 KiB of LDS, twelve wavefronts per CU);
+    // 16-bit visited table of the register-resident beam: 4096 entries (8 KiB of LDS, sixteen wavefronts per CU);
     // the id-to-tag mapping needs slots below 2^(tag_log2 + 13), so very large shards take a larger table
     const char* te = getenv("VDB_TAG_LOG2"); const int forced_tags = te ? atoi(te) : 0;
     a.tag_log2 = 12;
@@ -429,13 +429,14 @@ void vdb_index::search_batch_dev(const float* d_q, size_t nq, size_t top_k, size
     a.entry = slot_of.at(*entry_point); a.max_level = (uint32_t)current_max_level;
     auto fl = first_live_slot(); a.fallback_live = fl ? *fl : NONE32;
     a.ef = (uint32_t)ef_; a.top_k = (uint32_t)top_k; a.out = d_out; a.out_n = d_out_n; a.stats = d_stats;
-    if (!a.stats) {                       // the follow-up launches read the flags: one private array per stream
+    if (!a.stats) {                       // the kernels report per-query flags: one private array per stream
         auto& buf = s_stats_by_stream[s];
         buf.reserve(nq, s, false);
         a.stats = buf.p;
     }
     a.beam_width = beam_width();
-    // no host round trip on this path: an overflowing query reports QF_HASH_OVERFLOW in d_stats
+    // no host round trip on this path: a query of the LDS-list kernel (ef above 256) that outgrows every
+    // spill table reports QF_HASH_OVERFLOW in d_stats
     run_search(a, nq, s, false, d_q);
 }
 

@@ -47,7 +47,6 @@ struct SearchArgs {
     uint32_t fallback_live;      // smallest-id live slot, used when the entry is tombstoned
     uint32_t ef, top_k;
     uint32_t beam_width;         // register-resident beam: nodes expanded per step (1..4)
-    uint32_t only_flagged;       // 1: handle only queries whose stats carry QF_HASH_OVERFLOW (follow-up launches)
     uint32_t force_generic;      // 1: LDS-resident list with HBM spill tables even where the register beam applies
     vdb_scored_point* out;       // nq x top_k
     uint32_t* out_n;             // nq

@@ -397,9 +397,8 @@ struct Searcher {
     // ones and merges them by rank — the outcome of one insert per candidate in list order
     // (hnsw.rs:486-499); the permutation goes through `perm` in LDS once per 64 candidates.
     // width == 1 is the reference's strictly best-first order.  Euclidean keys are squared
-    // distances until the list is handed over in R (LDS).  The visited table is the LDS table
-    // alone: a query that fills it stops and is flagged (QF_HASH_OVERFLOW) for a launch with a
-    // larger table.
+    // distances until the list is handed over in R (LDS).  The visited set is the TagSet in LDS,
+    // which forgets ids instead of filling up (see TagSet): no query can outgrow it.
     __device__ __forceinline__ void beam_reg(uint32_t entry, uint32_t ef, uint32_t width) {
         constexpr int EMAX = 4;
         const int lane = lane_id();
@@ -795,7 +794,6 @@ struct Searcher {
         vis.tab = reinterpret_cast<uint32_t*>(smem + off);
         vis.spill = nullptr; vis.smask = 0; vis.sshift = 0; vis.scount = 0; vis.slimit = 0; vis.count = 0;
 
-        if (a.only_flagged && !(a.stats[q].flags & QF_HASH_OVERFLOW)) return;      // settled by an earlier launch
         if (lane == 0) a.out_n[q] = 0;
         if (a.entry == NONE32) return;                                     // hnsw.rs:515-518
 #ifdef VDB_TIMING
