@@ -430,3 +430,34 @@ def test_literal_filtered_search_reports_a_candidate_queue_that_is_too_small(vdb
     monkeypatch.setenv("VDB_LITERAL_CAND_CAP", "48")
     with pytest.raises(vdb.DBError, match="VDB_FILTER_MASKED"):
         seg.in_place_filtered_search(x[5], 10, f)
+
+
+@pytest.mark.parametrize("metric", [1, 2])
+def test_batch_insert_adds_the_filter_aware_edges(ora, vdb, metric):
+    """Segment batch inserts add the extra edges of hnsw.rs:210-325 with two launches per batch: every point gets
+    its self-edge (hnsw.rs:318) and, for its first key, edges to the m nearest points that share the value (posting
+    lists of at most 101 points are not sampled, so the set is exact); filtered search over the result finds the
+    passing neighbours."""
+    n, d, m = 3000, 16, 8
+    x = data(n, d, 111 + metric)
+    seg = vdb.Segment(vdb.HNSWIndex(metric, m, 32, 16, d, seed=4, arith=vdb.Arith.Strict, filter_mode=vdb.FilterMode.Masked))
+    pay = []
+    for i in range(n):
+        p = vdb.Payload(); p.set("cat", vdb.PayloadValue.Int(i % 60)); pay.append(p)
+    ids = seg.insert_batch(x, pay)
+    h = seg.hnsw()
+    row = {int(ids[i]): i for i in range(n)}
+    for i in range(0, n, 37):
+        nb = h.layer_neighbors(0, int(ids[i]))
+        assert int(ids[i]) in nb                                           # the self-edge
+        same = [j for j in range(n) if j % 60 == i % 60 and j != i]
+        sc = np.array([ora.score(x[i], x[j], metric) for j in same], np.float32)
+        order = np.argsort(-sc if metric == 1 else sc, kind="stable")[:m]
+        want = {int(ids[same[k]]) for k in order}
+        assert want <= set(nb), (i, sorted(want - set(nb)))
+        assert sum(1 for t in nb if t != int(ids[i]) and row[t] % 60 == i % 60) >= m
+    # the edges are symmetric (add_bidirectional_edge) and searchable
+    q = data(20, d, 113)
+    f = vdb.Filter.Match("cat", vdb.PayloadValue.Int(7))
+    got, gotn = seg.search_batch(q, 5, filter=f)
+    assert (gotn == 5).all() and all(row[int(t)] % 60 == 7 for t in got["id"].ravel())

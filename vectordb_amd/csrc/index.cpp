@@ -388,11 +388,11 @@ void vdb_index::search_batch(const float* q, size_t nq, size_t top_k, size_t ef_
     a.beam_width = beam_width();
     if (fa.bits) { a.pass_bits = fa.bits->d_pass.p; a.err_bits = fa.bits->d_err.p; }
     if (fa.mode == MODE_LITERAL) {
-        // hnsw.rs:639-689 never prunes its candidate heap: it holds every scored row that was not popped yet,
-        // at most one entry per row.  The queue gets what 2 GiB of scratch allow per query, between 16384 and
-        // 262144 entries and never more than the rows there are; a walk that needs more is reported.
+        // hnsw.rs:639-689 never prunes its candidate heap: it holds every scored row that was not popped yet.
+        // The queue is an unsorted array whose minimum is found by a scan, so its size also bounds the time a
+        // query can take: 16384 entries (one per row in smaller segments); a walk that needs more is reported.
         const char* ce = getenv("VDB_LITERAL_CAND_CAP");
-        size_t cap = std::min<size_t>(std::max<size_t>(((size_t)2 << 30) / (sizeof(vdb_scored_point) * nq), 16384), 262144);
+        size_t cap = 16384;
         if (ce && atoi(ce) > 0) cap = (size_t)atoi(ce);
         a.cand_cap = (uint32_t)std::min<size_t>(cap, ids.size() + 1);
         s_cand.reserve(nq * a.cand_cap, stream, false);
@@ -408,7 +408,7 @@ void vdb_index::search_batch(const float* q, size_t nq, size_t top_k, size_t ef_
         if (st[i].flags & QF_CAND_OVERFLOW)
             throw Failure(err_device("literal filtered search: the candidate queue of query " + std::to_string(i) + " outgrew " + std::to_string(a.cand_cap) +
                                      " entries (once ef passing rows are found the reference's walk scores every reachable row); "
-                                     "use fewer queries per call or VDB_FILTER_MASKED"));
+                                     "use VDB_FILTER_MASKED for segments of this size"));
         if (st[i].flags & QF_FILTER_ERROR) throw Failure(Error{VDB_ERR_INVALID_PAYLOAD, "@slot:" + std::to_string(st[i].expanded)});
     }
     if (stats) std::memcpy(stats, st.data(), nq * sizeof(vdb_query_stats));
@@ -546,6 +546,50 @@ std::vector<vdb_scored_point> vdb_index::search_from_row(uint32_t row_slot, uint
     VDB_HIP(hipStreamSynchronize(stream));
     out.resize(n);
     return out;
+}
+
+void vdb_index::search_from_rows(const std::vector<uint32_t>& rows, uint32_t entry_slot, size_t ef_search,
+                                 std::vector<vdb_scored_point>& out, std::vector<uint32_t>& cnt) {
+    const size_t nq = rows.size();
+    out.assign(nq * ef_search, vdb_scored_point{}); cnt.assign(nq, 0);
+    if (nq == 0) return;
+    std::lock_guard<std::mutex> lk(mu);
+    use_device();
+    sync_device();
+    std::vector<uint32_t> lv(nq, 0), off(nq + 1);
+    for (size_t i = 0; i <= nq; ++i) off[i] = (uint32_t)i;
+    s_slots.reserve(nq, stream, false); s_lvl.reserve(nq, stream, false); s_off.reserve(nq + 1, stream, false);
+    s_nb.reserve(nq * m, stream, false); s_nbc.reserve(nq, stream, false);
+    s_out.reserve(nq * ef_search, stream, false); s_n.reserve(nq, stream, false); s_stats.reserve(nq, stream, false);
+    VDB_HIP(hipMemcpyAsync(s_slots.p, rows.data(), nq * 4, hipMemcpyHostToDevice, stream));
+    VDB_HIP(hipMemcpyAsync(s_lvl.p, lv.data(), nq * 4, hipMemcpyHostToDevice, stream));
+    VDB_HIP(hipMemcpyAsync(s_off.p, off.data(), (nq + 1) * 4, hipMemcpyHostToDevice, stream));
+    SearchArgs a{};
+    a.g = view(); a.mode = MODE_BUILD; a.arith = opts.arith; a.query_slots = s_slots.p; a.nq = (uint32_t)nq;
+    a.entry = entry_slot; a.max_level = (uint32_t)current_max_level;
+    auto fl = first_live_slot(); a.fallback_live = fl ? *fl : NONE32;
+    a.ef = (uint32_t)ef_search; a.top_k = (uint32_t)ef_search; a.out = s_out.p; a.out_n = s_n.p; a.stats = s_stats.p;
+    a.beam_width = 1;
+    a.q_levels = s_lvl.p; a.nb_off = s_off.p; a.m = (uint32_t)m; a.nb_out = s_nb.p; a.nb_cnt = s_nbc.p;
+    run_search(a, nq, stream, true, nullptr);
+    VDB_HIP(hipMemcpyAsync(cnt.data(), s_n.p, nq * 4, hipMemcpyDeviceToHost, stream));
+    VDB_HIP(hipMemcpyAsync(out.data(), s_out.p, nq * ef_search * sizeof(vdb_scored_point), hipMemcpyDeviceToHost, stream));
+    VDB_HIP(hipStreamSynchronize(stream));
+}
+
+std::vector<float> vdb_index::score_pairs(const std::vector<uint32_t>& query_slots, const std::vector<uint32_t>& slots) {
+    std::vector<float> raw(slots.size());
+    if (slots.empty()) return raw;
+    std::lock_guard<std::mutex> lk(mu);
+    use_device();
+    sync_device();
+    s_qslots.reserve(slots.size(), stream, false); s_slots.reserve(slots.size(), stream, false); s_raw.reserve(slots.size(), stream, false);
+    VDB_HIP(hipMemcpyAsync(s_qslots.p, query_slots.data(), slots.size() * 4, hipMemcpyHostToDevice, stream));
+    VDB_HIP(hipMemcpyAsync(s_slots.p, slots.data(), slots.size() * 4, hipMemcpyHostToDevice, stream));
+    launch_score_pairs(view(), s_qslots.p, s_slots.p, (uint32_t)slots.size(), s_raw.p, stream);
+    VDB_HIP(hipMemcpyAsync(raw.data(), s_raw.p, raw.size() * 4, hipMemcpyDeviceToHost, stream));
+    VDB_HIP(hipStreamSynchronize(stream));
+    return raw;
 }
 
 // greedy_search_layer_unfiltered as a public accessor (hnsw.rs:333-368).  Searches run the descent

@@ -77,7 +77,7 @@ struct vdb_index {
     // per-call scratch (guarded by mu)
     mutable std::mutex mu;
     mutable vdb::DevBuf<float> s_q, s_raw, s_sub_vecs; mutable vdb::DevBuf<uint64_t> s_sub_ids; mutable vdb::DevBuf<vdb_scored_point> s_out, s_knn, s_cand;
-    mutable vdb::DevBuf<uint32_t> s_knn_words, s_n, s_slots, s_lvl, s_off, s_nb, s_nbc, s_hash, s_spill; mutable vdb::DevBuf<vdb_query_stats> s_stats;
+    mutable vdb::DevBuf<uint32_t> s_knn_words, s_n, s_slots, s_qslots, s_lvl, s_off, s_nb, s_nbc, s_hash, s_spill; mutable vdb::DevBuf<vdb_query_stats> s_stats;
     mutable std::map<hipStream_t, vdb::DevBuf<vdb_query_stats>> s_stats_by_stream;
 
     vdb_index(vdb_metric metric, size_t m, size_t ef, size_t cap, size_t dim, const vdb_options& o);
@@ -115,6 +115,11 @@ struct vdb_index {
     std::vector<float> score_rows(uint32_t query_slot, const std::vector<uint32_t>& slots);
     std::vector<float> score_all_rows(uint32_t query_slot);
     std::vector<vdb_scored_point> search_from_row(uint32_t row_slot, uint32_t entry_slot, size_t ef_search);
+    // the same for many stored rows in one launch: out holds rows.size() x ef_search records, cnt the valid ones per row
+    void search_from_rows(const std::vector<uint32_t>& rows, uint32_t entry_slot, size_t ef_search,
+                          std::vector<vdb_scored_point>& out, std::vector<uint32_t>& cnt);
+    // raw[i] = score(row query_slots[i], row slots[i]) in one launch
+    std::vector<float> score_pairs(const std::vector<uint32_t>& query_slots, const std::vector<uint32_t>& slots);
     uint32_t greedy_unfiltered(const float* q, uint32_t entry_slot, size_t level);
     std::vector<float> maybe_normalize(const float* v);
 
@@ -150,6 +155,7 @@ struct vdb_segment {
                       vdb_scored_point* out, uint32_t* out_n) const;
     const vdb::FilterBits& compile(const vdb_filter& f) const;
     void build_filter_aware_edges(uint64_t id, const vdb_payload& p, const std::vector<std::string>& keys);
+    void filter_aware_edges_batch(const std::vector<uint64_t>& pids, const vdb_payload* const* p);
 
  private:
     // useful_k: leading results the caller keeps when none of them is a tombstone (top_k may be an over-fetch)

@@ -134,6 +134,11 @@ __global__ void __launch_bounds__(64) score_rows_kernel(GraphView gv, uint32_t q
     if (i < n) raw[i] = strict_pair(gv.vecs + (size_t)query_slot * gv.stride, gv.vecs + (size_t)slots[i] * gv.stride, gv.dim, gv.metric, false);
 }
 
+__global__ void __launch_bounds__(64) score_pairs_kernel(GraphView gv, const uint32_t* __restrict__ qslots, const uint32_t* __restrict__ slots, uint32_t n, float* __restrict__ raw) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) raw[i] = strict_pair(gv.vecs + (size_t)qslots[i] * gv.stride, gv.vecs + (size_t)slots[i] * gv.stride, gv.dim, gv.metric, false);
+}
+
 // hnsw.rs:752-764: norm = sqrt(sequential sum of squares); zero norm leaves the row unchanged.
 __global__ void __launch_bounds__(64) normalize_rows_kernel(float* __restrict__ vecs, uint32_t stride, uint32_t dim, uint32_t first, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -177,6 +182,12 @@ void launch_score_scan(const float* queries, uint32_t nq, const float* base, uin
 void launch_score_rows(const GraphView& g, uint32_t query_slot, const uint32_t* slots, uint32_t n, int, float* raw, hipStream_t st) {
     if (n == 0) return;
     hipLaunchKernelGGL(score_rows_kernel, dim3((n + 63) / 64), dim3(64), 0, st, g, query_slot, slots, n, raw);
+    VDB_HIP(hipGetLastError());
+}
+
+void launch_score_pairs(const GraphView& g, const uint32_t* qslots, const uint32_t* slots, uint32_t n, float* raw, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(score_pairs_kernel, dim3((n + 63) / 64), dim3(64), 0, st, g, qslots, slots, n, raw);
     VDB_HIP(hipGetLastError());
 }
 

@@ -88,6 +88,8 @@ void launch_score_scan(const float* queries, uint32_t nq, const float* base, uin
                        int metric, int arith, float* out, hipStream_t s);
 // raw[i] = score(vecs[query_slot], vecs[slots[i]]) for i < n (stored rows on both sides).
 void launch_score_rows(const GraphView& g, uint32_t query_slot, const uint32_t* slots, uint32_t n, int arith, float* raw, hipStream_t s);
+// raw[i] = score(vecs[query_slots[i]], vecs[slots[i]]) for i < n: independent pairs of stored rows, strict arithmetic.
+void launch_score_pairs(const GraphView& g, const uint32_t* query_slots, const uint32_t* slots, uint32_t n, float* raw, hipStream_t s);
 // In-place row normalisation (hnsw.rs:752-764): rows first..first+n of `vecs`; zero-norm rows stay.
 void launch_normalize_rows(float* vecs, uint32_t stride, uint32_t dim, uint32_t first, uint32_t n, hipStream_t s);
 // Exact k-NN (strict arithmetic, (sort_key asc, id asc)) over live rows.

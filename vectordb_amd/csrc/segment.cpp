@@ -135,13 +135,121 @@ void vdb_segment::insert_batch(const float* v, size_t n, size_t len, const vdb_p
         }
     }
     ++payload_version;
-    for (size_t i = 0; i < n; ++i) {
-        if (!(p && p[i])) continue;
-        const std::vector<std::string> keys = p[i]->scalar_keys();
-        if (!keys.empty()) filter_aware_edges(*hnsw, payload_index, payloads, pids[i], *p[i], keys);
+    if (p) {
+        const size_t chunk = 65536;                        // bounds the host copies of the search results
+        for (size_t lo = 0; lo < n; lo += chunk) {
+            const size_t hi = std::min(n, lo + chunk);
+            filter_aware_edges_batch(std::vector<uint64_t>(pids.begin() + lo, pids.begin() + hi), p + lo);
+        }
     }
     next_id += n;
     if (out_ids) std::memcpy(out_ids, pids.data(), n * sizeof(uint64_t));
+}
+
+// hnsw.rs:210-325 for every point of a batch with two launches instead of two per point and key:
+// all sampled same-value pairs are scored at once, and every point's row searches the graph (as it
+// stands after the batch was linked, before any of these extra edges) once.  Per point the rules
+// are those of filter_aware_edges(): keys in ascending order, up to m nearest of <= 100 sampled
+// same-value points, then up to m same-value points among the search results, stop at m extras,
+// self-edge included (hnsw.rs:318).  The sample is drawn by position from the posting list
+// (Floyd's algorithm on the counter-based stream 2) instead of a reservoir pass over it.
+void vdb_segment::filter_aware_edges_batch(const std::vector<uint64_t>& pids, const vdb_payload* const* p) {
+    vdb_index& h = *hnsw;
+    if (h.current_max_level == 0) {                          // tiny graph: the per-point form scans every row (hnsw.rs:275-288)
+        for (size_t i = 0; i < pids.size(); ++i)
+            if (p[i]) { auto keys = p[i]->scalar_keys(); if (!keys.empty()) filter_aware_edges(h, payload_index, payloads, pids[i], *p[i], keys); }
+        return;
+    }
+    struct Job { size_t point; std::string key; const vdb_value* value; size_t first, count; };   // slice of the pair arrays
+    std::vector<size_t> pts; std::vector<std::vector<std::string>> keys_of;
+    for (size_t i = 0; i < pids.size(); ++i) {
+        if (!p[i]) continue;
+        std::vector<std::string> keys = p[i]->scalar_keys();
+        if (keys.empty()) continue;
+        pts.push_back(i); keys_of.push_back(std::move(keys));
+    }
+    if (pts.empty()) return;
+    const size_t m = h.m, amount = 100;
+    std::map<const std::set<uint64_t>*, std::vector<uint32_t>> posting;      // live slots of a posting list, in id order
+    std::vector<Job> jobs; std::vector<uint32_t> qs, ss;
+    for (size_t t = 0; t < pts.size(); ++t) {
+        const size_t i = pts[t];
+        const uint32_t self = h.slot_of.at(pids[i]);
+        for (const std::string& key : keys_of[t]) {
+            const vdb_value* value = p[i]->get(key);
+            if (!value) continue;
+            Job j{t, key, value, qs.size(), 0};
+            if (const std::set<uint64_t>* id_set = payload_index.query_exact(key, *value)) {
+                auto it = posting.find(id_set);
+                if (it == posting.end()) {
+                    std::vector<uint32_t> live; live.reserve(id_set->size());
+                    for (uint64_t pid : *id_set) { auto s = h.slot_of.find(pid); if (s != h.slot_of.end() && !h.deleted[s->second]) live.push_back(s->second); }
+                    it = posting.emplace(id_set, std::move(live)).first;
+                }
+                const std::vector<uint32_t>& live = it->second;
+                if (live.size() <= amount + 1) {
+                    for (uint32_t s : live) if (s != self) { qs.push_back(self); ss.push_back(s); }
+                } else {
+                    // amount + 1 distinct positions, so that dropping `self` (if drawn) still leaves `amount`
+                    std::set<size_t> chosen;
+                    const size_t N = live.size(), want = amount + 1;
+                    for (size_t r = N - want; r < N; ++r) {
+                        const size_t t2 = (size_t)(rng_draw(h.opts.seed, 2, h.sample_draws++) % (r + 1));
+                        if (!chosen.insert(t2).second) chosen.insert(r);
+                    }
+                    size_t taken = 0;
+                    for (size_t pos : chosen) { if (live[pos] == self || taken == amount) continue; qs.push_back(self); ss.push_back(live[pos]); ++taken; }
+                }
+            }
+            j.count = qs.size() - j.first;
+            jobs.push_back(std::move(j));
+        }
+    }
+    const std::vector<float> raw = h.score_pairs(qs, ss);
+    std::vector<uint32_t> rows(pts.size());
+    for (size_t t = 0; t < pts.size(); ++t) rows[t] = h.slot_of.at(pids[pts[t]]);
+    std::vector<vdb_scored_point> found; std::vector<uint32_t> found_n;
+    const size_t ef = h.ef;
+    h.search_from_rows(rows, h.slot_of.at(*h.entry_point), ef, found, found_n);
+
+    struct Scored { uint32_t slot; float raw; };
+    auto sort_raw = [&](std::vector<Scored>& v) {                                  // hnsw.rs:250-256 / :291-297 (stable)
+        if (h.metric == VDB_DOT) std::stable_sort(v.begin(), v.end(), [](const Scored& a, const Scored& b) { return a.raw > b.raw; });
+        else std::stable_sort(v.begin(), v.end(), [](const Scored& a, const Scored& b) { return a.raw < b.raw; });
+    };
+    size_t jb = 0;
+    for (size_t t = 0; t < pts.size(); ++t) {
+        const uint64_t point_id = pids[pts[t]];
+        const uint32_t self = rows[t];
+        std::set<uint64_t> extra;                                                  // DET-5
+        bool done = false;
+        for (; jb < jobs.size() && jobs[jb].point == t; ++jb) {
+            if (done) continue;
+            const Job& j = jobs[jb];
+            if (payload_index.query_exact(j.key, *j.value)) {
+                std::vector<Scored> scored;
+                for (size_t k = 0; k < j.count; ++k) scored.push_back({ss[j.first + k], raw[j.first + k]});
+                sort_raw(scored);
+                for (size_t k = 0; k < scored.size() && k < m; ++k) extra.insert(h.ids[scored[k].slot]);
+                if (extra.size() >= m) { done = true; continue; }
+            }
+            std::vector<Scored> candidates;
+            for (uint32_t k = 0; k < found_n[t]; ++k) { const vdb_scored_point& sp = found[t * ef + k]; candidates.push_back({h.slot_of.at(sp.id), sp.raw_score}); }
+            sort_raw(candidates);
+            size_t taken = 0;
+            for (const Scored& c : candidates) {
+                if (taken >= m) break;
+                auto pit = payloads.find(h.ids[c.slot]);
+                if (pit == payloads.end()) continue;
+                const vdb_value* v = pit->second.get(j.key);
+                if (!v || !(*v == *j.value)) continue;
+                extra.insert(h.ids[c.slot]); ++taken;
+            }
+            if (extra.size() >= m) done = true;
+        }
+        extra.insert(point_id);                                                     // hnsw.rs:318
+        for (uint64_t nid : extra) h.add_bidirectional_edge(0, self, h.slot_of.at(nid));
+    }
 }
 
 const float* vdb_segment::get_vector(uint64_t id) const {                           // segment.rs:64-69
