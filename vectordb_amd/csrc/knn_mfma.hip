@@ -183,6 +183,162 @@ __global__ void __launch_bounds__(256) knn_mfma_kernel(GraphView gv, const float
     }
 }
 
+// Rows longer than 256 floats: the contraction runs over the row in chunks of KC floats with the
+// accumulators kept in registers.  A block handles LT = 128 base rows (four 32x32 tiles per wave,
+// i.e. four independent MFMA chains) against MQ = 128 queries; per chunk the A slice (LT x KC) goes
+// through LDS (double buffered, one barrier per chunk) and every lane reads its 16 query values of
+// the chunk straight from global memory (the query block stays in L2).  Same epilogue and hand-over
+// as knn_mfma_kernel.  grid (n_chunks, ceil(nq / MQ)), 256 threads.
+constexpr int LT = 128, KC = 32, LDK = KC + 4;
+__global__ void __launch_bounds__(256) knn_mfma_long_kernel(GraphView gv, const float* __restrict__ queries, uint32_t nq,
+                                                           const float* __restrict__ scale, const float* __restrict__ bias,
+                                                           uint32_t* __restrict__ out_slots, uint32_t n_chunks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* At = reinterpret_cast<float*>(smem);                                  // 2 x LT x LDK
+    float* sc_t = At + 2 * LT * LDK;                                             // LT
+    float* bi_t = sc_t + LT;                                                     // LT
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(bi_t + LT);                      // MQ
+    uint2* buf = reinterpret_cast<uint2*>(cnt + MQ);                             // MQ x KNN_CAP {key bits, row}
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const uint32_t stride = gv.stride, dim = gv.dim;
+    const uint32_t q = blockIdx.y * MQ + wave * 32 + j;
+    const uint32_t ql = wave * 32 + j;
+    const bool qin = q < nq;
+    const float* qrow = queries + (size_t)(qin ? q : 0) * dim;
+    const bool qvec = (dim & 3u) == 0 && (reinterpret_cast<uintptr_t>(queries) & 15u) == 0;
+    const uint32_t nkc = (stride + KC - 1) / KC;
+
+    if (tid < MQ) cnt[tid] = 0;
+    float thr = INF_F;
+    const uint32_t per = (((gv.n + n_chunks - 1) / n_chunks) + LT - 1) / LT * LT;
+    const uint32_t r_begin = blockIdx.x * per, r_end = min(gv.n, r_begin + per);
+    const int lrow = tid >> 1, lhalf = tid & 1;          // loader: thread t brings 16 floats of tile row t / 2
+
+    auto compact = [&](uint32_t qi) -> float {
+        const uint32_t n = __builtin_amdgcn_readfirstlane(cnt[qi]);
+        uint2 e = make_uint2(0x7f800000u, 0xFFFFFFFFu);
+        if ((uint32_t)lane < n) e = buf[qi * KNN_CAP + lane];
+        const float k = __uint_as_float(e.x);
+        uint32_t rank = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const float ki = readlane_f(k, (int)i); const uint32_t ri = readlane_u(e.y, (int)i);
+            rank += (ki < k || (ki == k && ri < e.y)) ? 1u : 0u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if ((uint32_t)lane < n && rank < KNN_KP) buf[qi * KNN_CAP + rank] = e;
+        const uint32_t kept = n < KNN_KP ? n : KNN_KP;
+        if (lane == 0) cnt[qi] = kept;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint64_t last = __ballot((uint32_t)lane < n && rank == KNN_KP - 1);
+        return last ? readlane_f(k, __ffsll((unsigned long long)last) - 1) : INF_F;
+    };
+
+    for (uint32_t tb = r_begin; tb < r_end; tb += LT) {
+        float4 stage[4]; float bq[16], bn[16];
+        auto fetch_a = [&](uint32_t kc) {
+            const uint32_t r = tb + lrow;
+            const bool in = r < r_end;
+            const float* row = gv.vecs + (size_t)(in ? r : r_begin) * stride;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const uint32_t c = kc * KC + lhalf * 16 + v * 4;
+                stage[v] = (in && c < stride) ? *reinterpret_cast<const float4*>(row + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto fetch_b = [&](uint32_t kc, float* dst) {
+            const uint32_t d0 = kc * KC + h * 16;
+            if (qvec) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const uint32_t d = d0 + v * 4;
+                    const float4 x = (qin && d < dim) ? *reinterpret_cast<const float4*>(qrow + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    dst[4 * v] = x.x; dst[4 * v + 1] = x.y; dst[4 * v + 2] = x.z; dst[4 * v + 3] = x.w;
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) dst[v] = (qin && d0 + v < dim) ? qrow[d0 + v] : 0.f;
+            }
+        };
+        floatx16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+        __syncthreads();                                   // the previous tile's scale / bias and A slices are consumed
+        if (tid < LT) { const uint32_t rr = tb + tid; sc_t[tid] = rr < r_end ? scale[rr] : 0.f; bi_t[tid] = rr < r_end ? bias[rr] : INF_F; }
+        fetch_a(0); fetch_b(0, bq);
+        for (uint32_t kc = 0; kc < nkc; ++kc) {
+            float* Ab = At + (kc & 1u) * (LT * LDK);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) *reinterpret_cast<float4*>(Ab + lrow * LDK + lhalf * 16 + v * 4) = stage[v];
+            __syncthreads();
+            if (kc + 1 < nkc) { fetch_a(kc + 1); fetch_b(kc + 1, bn); }     // in flight during the contraction
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float* arow = Ab + (t * 32 + j) * LDK + h * 16;
+                float4 af[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) af[c] = *reinterpret_cast<const float4*>(arow + 4 * c);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c].x, bq[4 * c + 0], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c].y, bq[4 * c + 1], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c].z, bq[4 * c + 2], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c].w, bq[4 * c + 3], acc[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) bq[v] = bn[v];
+        }
+        // epilogue, one 32-row sub-tile at a time: acc[t][v] = q_j . x_i with i = t*32 + (v/4)*8 + h*4 + v%4
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float key[16];
+            bool any = false;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 s4 = *reinterpret_cast<const float4*>(sc_t + t * 32 + g4 * 8 + h * 4);
+                const float4 b4 = *reinterpret_cast<const float4*>(bi_t + t * 32 + g4 * 8 + h * 4);
+                key[g4 * 4 + 0] = __builtin_fmaf(acc[t][g4 * 4 + 0], s4.x, b4.x);
+                key[g4 * 4 + 1] = __builtin_fmaf(acc[t][g4 * 4 + 1], s4.y, b4.y);
+                key[g4 * 4 + 2] = __builtin_fmaf(acc[t][g4 * 4 + 2], s4.z, b4.z);
+                key[g4 * 4 + 3] = __builtin_fmaf(acc[t][g4 * 4 + 3], s4.w, b4.w);
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) any = any || key[v] < thr;
+            if (!qin) any = false;
+            if (__ballot(any)) {
+                if (any) {
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        if (key[v] < thr) {
+                            const uint32_t pos = atomicAdd(&cnt[ql], 1u);
+                            buf[ql * KNN_CAP + pos] = make_uint2(__float_as_uint(key[v]), tb + t * 32 + (v / 4) * 8 + h * 4 + (v % 4));
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                uint64_t need = __ballot(lane < 32 && cnt[wave * 32 + (lane & 31)] > KNN_TRIG);
+                while (need) {
+                    const int jj = __ffsll((unsigned long long)need) - 1; need &= need - 1;
+                    const float nt = compact(wave * 32 + jj);
+                    if (j == jj) thr = nt;
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int jj = 0; jj < 32; ++jj) {
+        const uint32_t qi = wave * 32 + jj, qg = blockIdx.y * MQ + qi;
+        if (qg >= nq) break;
+        if (cnt[qi] > KNN_KP) compact(qi);
+        const uint32_t n = cnt[qi];
+        if (lane < KNN_KP) out_slots[((size_t)qg * n_chunks + blockIdx.x) * KNN_KP + lane] = (uint32_t)lane < n ? buf[qi * KNN_CAP + lane].y : NONE32;
+    }
+}
+
 // One wave per query: strict scores of the candidate slots, ranked by (sort_key, id).
 struct TopKList {
     float* key; uint64_t* id; float* raw; uint32_t n, cap;
@@ -265,7 +421,7 @@ void launch_mfma(const GraphView& g, const float* queries, uint32_t nq, const fl
 
 }  // namespace
 
-bool knn_mfma_supported(const GraphView& g, uint32_t top_k) { return top_k >= 1 && top_k + 4 <= KNN_KP && g.stride <= 256 && g.n > 0; }
+bool knn_mfma_supported(const GraphView& g, uint32_t top_k) { return top_k >= 1 && top_k + 4 <= KNN_KP && g.stride <= MAX_DIM && g.n > 0; }
 uint32_t knn_mfma_chunks(uint32_t n, uint32_t nq) {
     // enough blocks to fill 256 CUs several times over, chunks of at least 4096 rows
     const uint32_t qblocks = (nq + MQ - 1) / MQ;
@@ -286,7 +442,11 @@ void launch_exact_knn_mfma(const GraphView& g, const float* queries, uint32_t nq
     VDB_HIP(hipGetLastError());
     if (g.stride <= 64) launch_mfma<32>(g, queries, nq, scale, bias, slots, n_chunks, st);
     else if (g.stride <= 128) launch_mfma<64>(g, queries, nq, scale, bias, slots, n_chunks, st);
-    else launch_mfma<128>(g, queries, nq, scale, bias, slots, n_chunks, st);
+    else if (g.stride <= 256) launch_mfma<128>(g, queries, nq, scale, bias, slots, n_chunks, st);
+    else {
+        const size_t lds = (size_t)2 * LT * LDK * 4 + 2 * LT * 4 + MQ * 4 + (size_t)MQ * KNN_CAP * 8;
+        hipLaunchKernelGGL(knn_mfma_long_kernel, dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, queries, nq, scale, bias, slots, n_chunks);
+    }
     VDB_HIP(hipGetLastError());
     const size_t lds = (size_t)g.stride * 4 + (size_t)top_k * 16;
     hipLaunchKernelGGL(knn_rerank_kernel, dim3(nq), dim3(64), lds, st, g, queries, top_k, slots, n_chunks * KNN_KP, out, out_n);
