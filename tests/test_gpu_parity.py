@@ -461,3 +461,24 @@ def test_batch_insert_adds_the_filter_aware_edges(ora, vdb, metric):
     f = vdb.Filter.Match("cat", vdb.PayloadValue.Int(7))
     got, gotn = seg.search_batch(q, 5, filter=f)
     assert (gotn == 5).all() and all(row[int(t)] % 60 == 7 for t in got["id"].ravel())
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("dim,k", [(64, 13), (128, 25), (768, 28), (96, 40)])
+def test_exact_knn_with_larger_top_k(ora, vdb, metric, dim, k):
+    """top_k up to 28 keeps 32 candidates per (query, chunk) in the matrix-core pass; above that every pair is scored
+    in strict arithmetic.  Both must equal the oracle's brute force bit for bit."""
+    n, nq = 12000, 150
+    xs = data(n, dim, 70 + dim, "clustered")
+    if metric == 0:
+        xs = xs / np.maximum(np.linalg.norm(xs, axis=1, keepdims=True), 1e-20).astype(np.float32)
+    ids = np.arange(n, dtype=np.uint64) * 5 + 2
+    dele = np.zeros(n, np.uint8); dele[::7] = 1
+    g = dict(ids=ids, levels=np.zeros(n, np.uint32), vectors=xs, deleted=dele, layers=[], entry=int(ids[1]), current_max_level=0)
+    q = data(nq, dim, 71, "clustered")
+    ho = ora.HNSWIndex(metric, 16, 64, 16, dim); ho.import_graph(g)
+    ref, refn = ho.exact_knn_batch(q, k)
+    hp = vdb.HNSWIndex(metric, 16, 64, 16, dim, arith=vdb.Arith.Fast); hp.import_graph(g)
+    got, gotn = hp.exact_knn_batch(q, k)
+    assert np.array_equal(refn, gotn) and np.array_equal(ref["id"], got["id"])
+    assert np.array_equal(ref["sort_key"].view(np.uint32), got["sort_key"].view(np.uint32))

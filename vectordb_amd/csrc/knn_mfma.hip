@@ -2,8 +2,8 @@
 // top-k' epilogue selects candidates, then every candidate is re-scored with the STRICT
 // arithmetic (metric.rs:15-35, one lane per row, sequential sums) and ranked by (sort_key, id), so
 // the returned keys are the strict ones bit for bit.  The candidate pass keeps, per query and per
-// chunk of the base set, the KNN_KP rows with the smallest *ranking key* (L2: |x|^2 - 2 q.x, dot:
-// -q.x, cosine: -q.x / |x|); it misses a true neighbour only if more than KNN_KP - top_k rows of
+// chunk of the base set, the KP (16 or 32) rows with the smallest *ranking key* (L2: |x|^2 - 2 q.x, dot:
+// -q.x, cosine: -q.x / |x|); it misses a true neighbour only if more than KP - top_k rows of
 // one chunk fall within the fp32 rounding error of the contraction (~1e-6 relative) of it.
 #include "device_common.hpp"
 #include <algorithm>
@@ -15,9 +15,10 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int MQ = 128;            // queries per block: 4 waves x 32 (the N side of the 32x32 tile)
 constexpr int MT = 32;             // base rows per tile (the M side)
-constexpr int KNN_KP = 16;         // candidates kept per (query, chunk)
-constexpr int KNN_CAP = 60;        // per-query buffer; compacted to KNN_KP once fewer than 32 entries (one tile of pushes) are free
-constexpr int KNN_TRIG = KNN_CAP - 32;
+// Candidates kept per (query, chunk): KP = 16 for top_k <= 12, 32 for top_k <= 28.  The per-query buffer of
+// CAP entries is compacted to KP once fewer than 32 entries (one tile of pushes) are free; it never
+// holds more than 64 entries, one per lane of the compacting wave.
+template <int KP> struct KnnBuf { static constexpr int CAP = KP == 16 ? 60 : 64, TRIG = CAP - 32; };
 constexpr float INF_F = __builtin_inff();
 
 // scale / bias turn a dot product into the ranking key: key = dot * scale[row] + bias[row].
@@ -43,11 +44,12 @@ __global__ void __launch_bounds__(256) knn_prepare_kernel(GraphView gv, float* _
 
 // grid (n_chunks, ceil(nq / MQ)), 256 threads.  KH = k-steps of the 32x32x2 MFMA = padded row / 2;
 // k-step s of lane half h multiplies dimension h*KH + s, so a lane reads KH contiguous floats.
-template <int KH>
+template <int KH, int KNN_KP>
 __global__ void __launch_bounds__(256) knn_mfma_kernel(GraphView gv, const float* __restrict__ queries, uint32_t nq,
                                                       const float* __restrict__ scale, const float* __restrict__ bias,
                                                       uint32_t* __restrict__ out_slots, uint32_t n_chunks) {
     constexpr int K = 2 * KH, LDA = K + 4;                     // padded tile row: conflict-free 16-byte reads
+    constexpr int KNN_CAP = KnnBuf<KNN_KP>::CAP, KNN_TRIG = KnnBuf<KNN_KP>::TRIG;
     constexpr int VPT = K / 32;                                // float4 per thread per tile (256 threads, 32 rows)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* At = reinterpret_cast<float*>(smem);                                  // MT x LDA
@@ -190,9 +192,11 @@ __global__ void __launch_bounds__(256) knn_mfma_kernel(GraphView gv, const float
 // the chunk straight from global memory (the query block stays in L2).  Same epilogue and hand-over
 // as knn_mfma_kernel.  grid (n_chunks, ceil(nq / MQ)), 256 threads.
 constexpr int LT = 128, KC = 32, LDK = KC + 4;
+template <int KNN_KP>
 __global__ void __launch_bounds__(256) knn_mfma_long_kernel(GraphView gv, const float* __restrict__ queries, uint32_t nq,
                                                            const float* __restrict__ scale, const float* __restrict__ bias,
                                                            uint32_t* __restrict__ out_slots, uint32_t n_chunks) {
+    constexpr int KNN_CAP = KnnBuf<KNN_KP>::CAP, KNN_TRIG = KnnBuf<KNN_KP>::TRIG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* At = reinterpret_cast<float*>(smem);                                  // 2 x LT x LDK
     float* sc_t = At + 2 * LT * LDK;                                             // LT
@@ -411,17 +415,29 @@ __global__ void __launch_bounds__(64) knn_rerank_kernel(GraphView gv, const floa
     if (lane == 0) out_n[q] = L.n;
 }
 
-template <int KH>
+template <int KH, int KP>
 void launch_mfma(const GraphView& g, const float* queries, uint32_t nq, const float* scale, const float* bias, uint32_t* slots,
                  uint32_t n_chunks, hipStream_t st) {
     constexpr int K = 2 * KH;
-    const size_t lds = (size_t)MT * (K + 4) * 4 + 2 * MT * 4 + MQ * 4 + (size_t)MQ * KNN_CAP * 8;
-    hipLaunchKernelGGL((knn_mfma_kernel<KH>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, queries, nq, scale, bias, slots, n_chunks);
+    const size_t lds = (size_t)MT * (K + 4) * 4 + 2 * MT * 4 + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8;
+    hipLaunchKernelGGL((knn_mfma_kernel<KH, KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, queries, nq, scale, bias, slots, n_chunks);
 }
+template <int KP>
+void launch_mfma_any(const GraphView& g, const float* queries, uint32_t nq, const float* scale, const float* bias, uint32_t* slots,
+                     uint32_t n_chunks, hipStream_t st) {
+    if (g.stride <= 64) launch_mfma<32, KP>(g, queries, nq, scale, bias, slots, n_chunks, st);
+    else if (g.stride <= 128) launch_mfma<64, KP>(g, queries, nq, scale, bias, slots, n_chunks, st);
+    else if (g.stride <= 256) launch_mfma<128, KP>(g, queries, nq, scale, bias, slots, n_chunks, st);
+    else {
+        const size_t lds = (size_t)2 * LT * LDK * 4 + 2 * LT * 4 + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8;
+        hipLaunchKernelGGL((knn_mfma_long_kernel<KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, queries, nq, scale, bias, slots, n_chunks);
+    }
+}
+inline uint32_t knn_kp(uint32_t top_k) { return top_k + 4 <= 16 ? 16u : 32u; }
 
 }  // namespace
 
-bool knn_mfma_supported(const GraphView& g, uint32_t top_k) { return top_k >= 1 && top_k + 4 <= KNN_KP && g.stride <= MAX_DIM && g.n > 0; }
+bool knn_mfma_supported(const GraphView& g, uint32_t top_k) { return top_k >= 1 && top_k + 4 <= 32 && g.stride <= MAX_DIM && g.n > 0; }
 uint32_t knn_mfma_chunks(uint32_t n, uint32_t nq) {
     // enough blocks to fill 256 CUs several times over, chunks of at least 4096 rows
     const uint32_t qblocks = (nq + MQ - 1) / MQ;
@@ -429,7 +445,7 @@ uint32_t knn_mfma_chunks(uint32_t n, uint32_t nq) {
     c = std::min<uint32_t>(c, std::max<uint32_t>(1, n / 4096));
     return std::max<uint32_t>(1, std::min<uint32_t>(c, 64));
 }
-size_t knn_mfma_scratch_words(uint32_t n, uint32_t nq) { return 2 * (size_t)n + (size_t)nq * knn_mfma_chunks(n, nq) * KNN_KP; }
+size_t knn_mfma_scratch_words(uint32_t n, uint32_t nq) { return 2 * (size_t)n + (size_t)nq * knn_mfma_chunks(n, nq) * 32; }
 
 // scratch: knn_mfma_scratch_words() dwords = [scale n][bias n][candidate slots]
 void launch_exact_knn_mfma(const GraphView& g, const float* queries, uint32_t nq, uint32_t top_k, vdb_scored_point* out, uint32_t* out_n,
@@ -440,16 +456,12 @@ void launch_exact_knn_mfma(const GraphView& g, const float* queries, uint32_t nq
     uint32_t* slots = scratch + 2 * (size_t)g.n;
     hipLaunchKernelGGL(knn_prepare_kernel, dim3((g.n + 31) / 32), dim3(256), 0, st, g, scale, bias);
     VDB_HIP(hipGetLastError());
-    if (g.stride <= 64) launch_mfma<32>(g, queries, nq, scale, bias, slots, n_chunks, st);
-    else if (g.stride <= 128) launch_mfma<64>(g, queries, nq, scale, bias, slots, n_chunks, st);
-    else if (g.stride <= 256) launch_mfma<128>(g, queries, nq, scale, bias, slots, n_chunks, st);
-    else {
-        const size_t lds = (size_t)2 * LT * LDK * 4 + 2 * LT * 4 + MQ * 4 + (size_t)MQ * KNN_CAP * 8;
-        hipLaunchKernelGGL(knn_mfma_long_kernel, dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, queries, nq, scale, bias, slots, n_chunks);
-    }
+    const uint32_t kp = knn_kp(top_k);
+    if (kp == 16) launch_mfma_any<16>(g, queries, nq, scale, bias, slots, n_chunks, st);
+    else launch_mfma_any<32>(g, queries, nq, scale, bias, slots, n_chunks, st);
     VDB_HIP(hipGetLastError());
     const size_t lds = (size_t)g.stride * 4 + (size_t)top_k * 16;
-    hipLaunchKernelGGL(knn_rerank_kernel, dim3(nq), dim3(64), lds, st, g, queries, top_k, slots, n_chunks * KNN_KP, out, out_n);
+    hipLaunchKernelGGL(knn_rerank_kernel, dim3(nq), dim3(64), lds, st, g, queries, top_k, slots, n_chunks * kp, out, out_n);
     VDB_HIP(hipGetLastError());
 }
 
