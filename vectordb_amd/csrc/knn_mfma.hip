@@ -15,10 +15,11 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int MQ = 128;            // queries per block: 4 waves x 32 (the N side of the 32x32 tile)
 constexpr int MT = 32;             // base rows per tile (the M side)
-// Candidates kept per (query, chunk): KP = 16 for top_k <= 12, 32 for top_k <= 28.  The per-query buffer of
-// CAP entries is compacted to KP once fewer than 32 entries (one tile of pushes) are free; it never
-// holds more than 64 entries, one per lane of the compacting wave.
-template <int KP> struct KnnBuf { static constexpr int CAP = KP == 16 ? 60 : 64, TRIG = CAP - 32; };
+// Candidates kept per (query, chunk): KP = 16 for top_k <= 12, 32 for top_k <= 28.  A 32-row tile is
+// pushed in two halves of at most 16 entries per query; the per-query buffer of CAP entries is
+// compacted to KP once fewer than 16 entries are free and never holds more than 64 entries, one per
+// lane of the compacting wave.
+template <int KP> struct KnnBuf { static constexpr int CAP = KP == 16 ? 40 : 64, TRIG = CAP - 16; };
 constexpr float INF_F = __builtin_inff();
 
 // scale / bias turn a dot product into the ranking key: key = dot * scale[row] + bias[row].
@@ -141,7 +142,6 @@ __global__ void __launch_bounds__(256) knn_mfma_kernel(GraphView gv, const float
         }
         // epilogue: acc[v] = q_j . x_i with i = (v/4)*8 + h*4 + v%4
         float key[16];
-        bool any = false;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const float4 s4 = *reinterpret_cast<const float4*>(sc_t + g4 * 8 + h * 4);
@@ -152,25 +152,29 @@ __global__ void __launch_bounds__(256) knn_mfma_kernel(GraphView gv, const float
             key[g4 * 4 + 3] = __builtin_fmaf(acc[g4 * 4 + 3], s4.w, b4.w);
         }
 #pragma unroll
-        for (int v = 0; v < 16; ++v) any = any || key[v] < thr;
-        if (q >= nq) any = false;
-        if (__ballot(any)) {
-            if (any) {
+        for (int hv = 0; hv < 2; ++hv) {           // rows in two halves: at most 16 pushes per query between compactions
+            bool any2 = false;
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    if (key[v] < thr) {
-                        const uint32_t pos = atomicAdd(&cnt[ql], 1u);
-                        buf[ql * KNN_CAP + pos] = make_uint2(__float_as_uint(key[v]), tb + (v / 4) * 8 + h * 4 + (v % 4));
+            for (int v = hv * 8; v < hv * 8 + 8; ++v) any2 = any2 || key[v] < thr;
+            if (q >= nq) any2 = false;
+            if (__ballot(any2)) {
+                if (any2) {
+#pragma unroll
+                    for (int v = hv * 8; v < hv * 8 + 8; ++v) {
+                        if (key[v] < thr) {
+                            const uint32_t pos = atomicAdd(&cnt[ql], 1u);
+                            buf[ql * KNN_CAP + pos] = make_uint2(__float_as_uint(key[v]), tb + (v / 4) * 8 + h * 4 + (v % 4));
+                        }
                     }
                 }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            // queries of this wave whose buffer could not take another tile
-            uint64_t need = __ballot(lane < 32 && cnt[wave * 32 + (lane & 31)] > KNN_TRIG);
-            while (need) {
-                const int jj = __ffsll((unsigned long long)need) - 1; need &= need - 1;
-                const float nt = compact(wave * 32 + jj);
-                if (j == jj) thr = nt;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                // queries of this wave whose buffer could not take another half tile
+                uint64_t need = __ballot(lane < 32 && cnt[wave * 32 + (lane & 31)] > KNN_TRIG);
+                while (need) {
+                    const int jj = __ffsll((unsigned long long)need) - 1; need &= need - 1;
+                    const float nt = compact(wave * 32 + jj);
+                    if (j == jj) thr = nt;
+                }
             }
         }
     }
@@ -300,7 +304,6 @@ __global__ void __launch_bounds__(256) knn_mfma_long_kernel(GraphView gv, const 
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             float key[16];
-            bool any = false;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const float4 s4 = *reinterpret_cast<const float4*>(sc_t + t * 32 + g4 * 8 + h * 4);
@@ -311,24 +314,28 @@ __global__ void __launch_bounds__(256) knn_mfma_long_kernel(GraphView gv, const 
                 key[g4 * 4 + 3] = __builtin_fmaf(acc[t][g4 * 4 + 3], s4.w, b4.w);
             }
 #pragma unroll
-            for (int v = 0; v < 16; ++v) any = any || key[v] < thr;
-            if (!qin) any = false;
-            if (__ballot(any)) {
-                if (any) {
+            for (int hv = 0; hv < 2; ++hv) {
+                bool any2 = false;
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) {
-                        if (key[v] < thr) {
-                            const uint32_t pos = atomicAdd(&cnt[ql], 1u);
-                            buf[ql * KNN_CAP + pos] = make_uint2(__float_as_uint(key[v]), tb + t * 32 + (v / 4) * 8 + h * 4 + (v % 4));
+                for (int v = hv * 8; v < hv * 8 + 8; ++v) any2 = any2 || key[v] < thr;
+                if (!qin) any2 = false;
+                if (__ballot(any2)) {
+                    if (any2) {
+#pragma unroll
+                        for (int v = hv * 8; v < hv * 8 + 8; ++v) {
+                            if (key[v] < thr) {
+                                const uint32_t pos = atomicAdd(&cnt[ql], 1u);
+                                buf[ql * KNN_CAP + pos] = make_uint2(__float_as_uint(key[v]), tb + t * 32 + (v / 4) * 8 + h * 4 + (v % 4));
+                            }
                         }
                     }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                uint64_t need = __ballot(lane < 32 && cnt[wave * 32 + (lane & 31)] > KNN_TRIG);
-                while (need) {
-                    const int jj = __ffsll((unsigned long long)need) - 1; need &= need - 1;
-                    const float nt = compact(wave * 32 + jj);
-                    if (j == jj) thr = nt;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    uint64_t need = __ballot(lane < 32 && cnt[wave * 32 + (lane & 31)] > KNN_TRIG);
+                    while (need) {
+                        const int jj = __ffsll((unsigned long long)need) - 1; need &= need - 1;
+                        const float nt = compact(wave * 32 + jj);
+                        if (j == jj) thr = nt;
+                    }
                 }
             }
         }
