@@ -172,7 +172,16 @@ void vdb_index::patch_layer0() {
     h_deg0.resize(n, 0);
     std::vector<uint32_t> idx, blocks(dirty0.size() * ADJ_BLOCK), ovf, tmp;
     idx.reserve(dirty0.size());
-    for (uint32_t s : dirty0) {
+    const HostLayer* L0 = layers.empty() ? nullptr : &layers[0];
+    auto l0 = [&](size_t i) -> const std::vector<uint32_t>* {
+        const uint32_t s = dirty0[i];
+        return (L0 && s < L0->idx.size() && L0->idx[s] >= 0) ? &L0->lists[L0->idx[s]] : nullptr;
+    };
+    for (size_t di = 0; di < dirty0.size(); ++di) {
+        const uint32_t s = dirty0[di];
+        // the lists lie at random places of the host mirror: request the header 16 ahead, the contents 8 ahead
+        if (di + 16 < dirty0.size()) { if (auto* v = l0(di + 16)) __builtin_prefetch(v); }
+        if (di + 8 < dirty0.size()) { if (auto* v = l0(di + 8)) if (!v->empty()) { __builtin_prefetch(v->data()); __builtin_prefetch(v->data() + v->size() - 1); } }
         const std::vector<uint32_t>* lst = list(0, s);
         if (lst) clean_list(*lst, s, tmp); else tmp.clear();
         fill_block(&blocks[idx.size() * ADJ_BLOCK], tmp, ovf, ovf_used);
@@ -720,7 +729,27 @@ void vdb_index::insert_batch(const uint64_t* pids, const float* v, size_t n, siz
         std::vector<uint32_t> slots(rid.size());
         for (size_t k = 0; k < rid.size(); ++k) slots[k] = first + (uint32_t)k;
         BuildResult br = build_search(slots, ep);
-        for (size_t k = 0; k < slots.size(); ++k) link_point(slots[k], br, k);
+        // linking touches ~17 lists per point at random places of the host mirror: the list headers of the
+        // point 16 ahead and the list contents of the point 8 ahead are requested before they are needed
+        auto ahead = [&](size_t k, bool contents) {
+            const size_t level = levels[slots[k]];
+            for (size_t l = 0; l <= level && l < layers.size(); ++l) {
+                const HostLayer& L = layers[l];
+                const size_t row = br.off[k] + l;
+                for (uint32_t j = 0; j < br.cnt[row]; ++j) {
+                    const uint32_t nb = br.nb[row * m + j];
+                    if (nb >= L.idx.size() || L.idx[nb] < 0) continue;
+                    const std::vector<uint32_t>& v = L.lists[L.idx[nb]];
+                    if (!contents) __builtin_prefetch(&v);
+                    else if (!v.empty()) { __builtin_prefetch(v.data()); __builtin_prefetch(v.data() + v.size() - 1, 1); }
+                }
+            }
+        };
+        for (size_t k = 0; k < slots.size(); ++k) {
+            if (k + 16 < slots.size()) ahead(k + 16, false);
+            if (k + 8 < slots.size()) ahead(k + 8, true);
+            link_point(slots[k], br, k);
+        }
     }
 }
 
