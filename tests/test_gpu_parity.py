@@ -482,3 +482,32 @@ def test_exact_knn_with_larger_top_k(ora, vdb, metric, dim, k):
     got, gotn = hp.exact_knn_batch(q, k)
     assert np.array_equal(refn, gotn) and np.array_equal(ref["id"], got["id"])
     assert np.array_equal(ref["sort_key"].view(np.uint32), got["sort_key"].view(np.uint32))
+
+
+def test_incremental_device_copy_equals_a_fresh_pack(vdb, monkeypatch):
+    """Batched and single inserts keep the device copy of layer 0 current with block patches for new and re-linked
+    lists and single appended entries for reverse edges.  With VDB_VERIFY_DEVICE=1 every sync compares all blocks
+    with a fresh pack of the host lists; and an index that imports the exported graph (one full pack) must answer
+    every query exactly like the incrementally maintained one."""
+    monkeypatch.setenv("VDB_VERIFY_DEVICE", "1")
+    n, d, k = 24000, 24, 10
+    x = data(n + 300, d, 121, "clustered")
+    a = vdb.HNSWIndex(2, 16, 64, 16, d, seed=12)
+    for lo in range(0, n, 5000):
+        a.insert_batch(np.arange(lo, min(n, lo + 5000), dtype=np.uint64), x[lo:min(n, lo + 5000)])
+        a.sync_device()
+    for i in range(n, n + 300):                                  # single inserts on top
+        a.insert(i, x[i])
+        if i % 50 == 0: a.sync_device()
+    a.add_bidirectional_edge(0, 5, 17); a.add_bidirectional_edge(0, 5, 17)    # repeated edge: the list is re-packed as a whole
+    a.mark_deleted(40)
+    a.sync_device()
+    info = a.device_info()
+    b = vdb.HNSWIndex(2, 16, 64, 16, d, seed=12); b.import_graph(a.export_graph()); b.sync_device()
+    assert b.device_info()["l0_edges"] == info["l0_edges"]
+    q = data(400, d, 122, "clustered")
+    for ef in (32, 150):
+        ra, na, sa = a.search_batch(q, k, ef_search=ef, with_stats=True)
+        rb, nb, sb = b.search_batch(q, k, ef_search=ef, with_stats=True)
+        assert np.array_equal(na, nb) and np.array_equal(ra["id"], rb["id"]) and np.array_equal(sa["expanded"], sb["expanded"])
+        assert np.array_equal(ra["sort_key"].view(np.uint32), rb["sort_key"].view(np.uint32))

@@ -8,10 +8,13 @@ from bench import clustered, recall_at_k
 import vectordb_amd
 from oracle import pyoracle
 
+# usage: build_quality.py [n] [dim] [number of Gaussian centres]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
-d, nq, k = 128, 2000, 10
+d = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+nq, k = 2000, 10
 vdb, ora = vectordb_amd.api(), pyoracle.load()
-centres = np.random.default_rng(0xC2).uniform(0, 128, size=(max(16, n * 4096 // 1_000_000), d)).astype(np.float32)
+n_centres = int(sys.argv[3]) if len(sys.argv) > 3 else max(16, n * 4096 // 1_000_000)
+centres = np.random.default_rng(0xC2).uniform(0, 128, size=(n_centres, d)).astype(np.float32)
 base = clustered(n, d, 1, centres); queries = clustered(nq, d, 2, centres)
 ids = np.arange(n, dtype=np.uint64)
 M = vdb.DistanceMetric.Euclidean
@@ -27,7 +30,7 @@ to = time.time() - t0
 hs = vdb.HNSWIndex(M, 16, 64, 16, d, seed=7)
 hs.import_graph(ho.export_graph())
 exact, _ = hb.exact_knn_batch(queries, k)
-print(f"n={n}: batched GPU build {tb:.1f}s, sequential oracle build {to:.1f}s")
+print(f"n={n} d={d} centres={n_centres} ({n // n_centres} points per centre): batched GPU build {tb:.1f}s, sequential oracle build {to:.1f}s")
 for name, h in (("batched", hb), ("sequential", hs)):
     info = h.device_info()
     for ef in (16, 32, 64, 128, 256):

@@ -145,6 +145,7 @@ void vdb_index::pack_layer0_full() {
     const size_t n = ids.size();
     std::vector<uint32_t> adj0(n * ADJ_BLOCK, 0), ovf, tmp;
     h_deg0.assign(n, 0);
+    delta_slot.clear(); delta_pos.clear(); delta_val.clear();      // the lists already hold the appended entries
     size_t edges = 0;
     if (!layers.empty()) {
         const HostLayer& L0 = layers[0];
@@ -170,6 +171,17 @@ void vdb_index::patch_layer0() {
     const size_t n = ids.size();
     d_adj0.reserve(std::max<size_t>(n, 1) * ADJ_BLOCK, stream, true);
     h_deg0.resize(n, 0);
+    if (!delta_slot.empty()) {
+        // appended entries first; a list that was also edited some other way is re-packed below as a whole
+        const size_t nd = delta_slot.size();
+        s_delta.reserve(3 * nd, stream, false);
+        VDB_HIP(hipMemcpyAsync(s_delta.p, delta_slot.data(), nd * 4, hipMemcpyHostToDevice, stream));
+        VDB_HIP(hipMemcpyAsync(s_delta.p + nd, delta_pos.data(), nd * 4, hipMemcpyHostToDevice, stream));
+        VDB_HIP(hipMemcpyAsync(s_delta.p + 2 * nd, delta_val.data(), nd * 4, hipMemcpyHostToDevice, stream));
+        launch_patch_entries(d_adj0.p, s_delta.p, s_delta.p + nd, s_delta.p + 2 * nd, (uint32_t)nd, stream);
+        VDB_HIP(hipStreamSynchronize(stream));             // the host vectors are reused
+        delta_slot.clear(); delta_pos.clear(); delta_val.clear();
+    }
     std::vector<uint32_t> idx, blocks(dirty0.size() * ADJ_BLOCK), ovf, tmp;
     idx.reserve(dirty0.size());
     const HostLayer* L0 = layers.empty() ? nullptr : &layers[0];
@@ -200,6 +212,30 @@ void vdb_index::patch_layer0() {
         launch_patch_blocks(d_adj0.p, s_patch_idx.p, s_patch_blk.p, (uint32_t)idx.size(), stream);
     }
     VDB_HIP(hipStreamSynchronize(stream));
+}
+
+// Diagnostic (VDB_VERIFY_DEVICE=1): every layer-0 block on the device must describe the packed form of the
+// host list (degree, inline neighbours, overflow run), whatever mix of block patches and appended entries built it.
+void vdb_index::verify_layer0() {
+    const size_t n = ids.size();
+    if (n == 0) return;
+    std::vector<uint32_t> dev(n * ADJ_BLOCK), ovf(std::max<size_t>(ovf_used, 1)), tmp;
+    VDB_HIP(hipMemcpyAsync(dev.data(), d_adj0.p, dev.size() * 4, hipMemcpyDeviceToHost, stream));
+    if (ovf_used) VDB_HIP(hipMemcpyAsync(ovf.data(), d_ovf.p, ovf_used * 4, hipMemcpyDeviceToHost, stream));
+    VDB_HIP(hipStreamSynchronize(stream));
+    size_t edges = 0;
+    for (uint32_t s = 0; s < n; ++s) {
+        const std::vector<uint32_t>* lst = list(0, s);
+        if (lst) clean_list(*lst, s, tmp); else tmp.clear();
+        const uint32_t* blk = &dev[(size_t)s * ADJ_BLOCK];
+        bool ok = blk[0] == tmp.size() && h_deg0[s] == tmp.size();
+        for (size_t i = 0; ok && i < tmp.size(); ++i)
+            ok = (i < ADJ_INLINE ? blk[1 + i] : ovf[blk[63] + (i - ADJ_INLINE)]) == tmp[i];
+        if (!ok) throw Failure(err_device("layer-0 block of slot " + std::to_string(s) + " differs from the host list (device degree " +
+                                          std::to_string(blk[0]) + ", host " + std::to_string(tmp.size()) + ")"));
+        edges += tmp.size();
+    }
+    if (edges != l0_edges) throw Failure(err_device("layer-0 edge count " + std::to_string(l0_edges) + " differs from the lists' " + std::to_string(edges)));
 }
 
 // Upper layers from scratch (they hold about 1/M of the points): descriptor lists for the LDS-list
@@ -258,14 +294,30 @@ void vdb_index::pack_upper() {
     upper_slots = n;
 }
 
-void vdb_index::sync_device() {
+void vdb_index::sync_device(bool for_build) {
     use_device();
     const size_t n = ids.size();
     if (graph_dirty) {
-        const bool full = need_full || d_adj0.cap == 0 || dirty0.size() * 8 > n;
+        // a whole re-pack only when most blocks changed: patching a block costs about as much as packing it
+        const bool full = need_full || d_adj0.cap == 0 || dirty0.size() * 2 > n;
         if (full) pack_layer0_full(); else patch_layer0();
-        if (full || upper_dirty) pack_upper();
-        else if (upper_slots != n) {             // new points without upper lists: default entries only
+        bool upper_now = full || upper_dirty;
+        if (upper_now && !full && for_build && d_upper_base.cap != 0) {
+            // between rounds of the batched builder: keep the packed upper layers until they lack 1/16 of their
+            // lists or the entry point moved (every search of a caller still sees them complete)
+            size_t lists = 0;
+            for (size_t l = 1; l < layers.size(); ++l) lists += layers[l].lists.size();
+            const uint64_t ep = entry_point ? *entry_point : ~0ull;
+            if (ep == entry_at_pack && (lists - upper_lists_packed) * 16 <= upper_lists_packed) upper_now = false;
+        }
+        if (upper_now) {
+            pack_upper();
+            upper_lists_packed = 0;
+            for (size_t l = 1; l < layers.size(); ++l) upper_lists_packed += layers[l].lists.size();
+            entry_at_pack = entry_point ? *entry_point : ~0ull;
+            upper_dirty = false;
+        }
+        if (!upper_now && upper_slots != n) {    // new points without (packed) upper lists: default entries only
             d_upper_base.reserve(n, stream, true); d_upper_cnt.reserve(n, stream, true);
             std::vector<uint32_t> nb(n - upper_slots, NONE32);
             VDB_HIP(hipMemcpyAsync(d_upper_base.p + upper_slots, nb.data(), nb.size() * 4, hipMemcpyHostToDevice, stream));
@@ -274,9 +326,10 @@ void vdb_index::sync_device() {
             upper_slots = n;
         }
         for (uint32_t s : dirty0) dirty0_mark[s] = 0;
-        dirty0.clear(); upper_dirty = false; need_full = false;
+        dirty0.clear(); need_full = false;
+        if (getenv("VDB_VERIFY_DEVICE")) verify_layer0();
         device_bytes = n * (size_t)stride * 4 + n * 8 + n * ADJ_BLOCK * 4 + ovf_used * 4 + n * 5 + upper_words * 4;
-        graph_dirty = false;
+        graph_dirty = upper_dirty;               // a postponed upper re-pack keeps the copy stale for other callers
     }
     if (deleted_dirty) {
         if (n_deleted) {
@@ -645,7 +698,7 @@ uint32_t vdb_index::greedy_unfiltered(const float* q, uint32_t entry_slot, size_
 
 // One construction launch: for every new slot, greedy descent above its level and an ef-beam on
 // each layer from its level down to 0 (hnsw.rs:169-199); returns the first M results per layer.
-vdb_index::BuildResult vdb_index::build_search(const std::vector<uint32_t>& slots, uint32_t entry_slot) {
+vdb_index::BuildResult vdb_index::build_search(const std::vector<uint32_t>& slots, uint32_t entry_slot, bool lazy_upper) {
     BuildResult br;
     const size_t nq = slots.size();
     br.off.resize(nq + 1); br.off[0] = 0;
@@ -655,7 +708,7 @@ vdb_index::BuildResult vdb_index::build_search(const std::vector<uint32_t>& slot
     br.nb.assign(rows * m, 0); br.cnt.assign(rows, 0);
     std::lock_guard<std::mutex> lk(mu);
     use_device();
-    sync_device();
+    sync_device(lazy_upper);
     s_slots.reserve(nq, stream, false); s_lvl.reserve(nq, stream, false); s_off.reserve(nq + 1, stream, false);
     s_nb.reserve(rows * m, stream, false); s_nbc.reserve(rows, stream, false);
     s_n.reserve(nq, stream, false); s_stats.reserve(nq, stream, false);
@@ -687,6 +740,18 @@ void vdb_index::link_point(uint32_t s, const BuildResult& br, size_t qi) {
         if (std::find(linked.begin(), linked.end(), s) == linked.end()) linked.push_back(s);
         list_or_default(l, s) = linked;
         for (uint32_t nb : neighbors) {
+            // layer 0, device block of nb current and not full: the new neighbour is an append at a known
+            // position of the packed list (s is not in the list and is not nb itself), sent as one entry
+            if (l == 0 && !need_full && nb != s && nb < h_deg0.size() && nb < dirty0_mark.size() && !dirty0_mark[nb] && h_deg0[nb] < ADJ_INLINE &&
+                nb < layers[0].idx.size() && layers[0].idx[nb] >= 0) {
+                std::vector<uint32_t>& e = layers[0].lists[layers[0].idx[nb]];
+                if (std::find(e.begin(), e.end(), s) == e.end()) {
+                    e.push_back(s);
+                    delta_slot.push_back(nb); delta_pos.push_back(h_deg0[nb]++); delta_val.push_back(s);
+                    ++l0_edges; graph_dirty = true;
+                }
+                continue;
+            }
             std::vector<uint32_t>& e = list_or_default(l, nb);
             if (std::find(e.begin(), e.end(), s) == e.end()) e.push_back(s);
         }
@@ -728,7 +793,7 @@ void vdb_index::insert_batch(const uint64_t* pids, const float* v, size_t n, siz
         const uint32_t first = append_rows(rid.data(), rv.data(), rid.size());
         std::vector<uint32_t> slots(rid.size());
         for (size_t k = 0; k < rid.size(); ++k) slots[k] = first + (uint32_t)k;
-        BuildResult br = build_search(slots, ep);
+        BuildResult br = build_search(slots, ep, true);
         // linking touches ~17 lists per point at random places of the host mirror: the list headers of the
         // point 16 ahead and the list contents of the point 8 ahead are requested before they are needed
         auto ahead = [&](size_t k, bool contents) {

@@ -71,8 +71,11 @@ struct vdb_index {
     // device, the part of `ovf` in use; upper layers are re-packed as a whole when any of their lists changed
     std::vector<uint32_t> dirty0, h_deg0, clean_stamp; std::vector<uint8_t> dirty0_mark;
     uint32_t clean_epoch = 0; bool upper_dirty = true, need_full = true;
-    size_t ovf_used = 0, upper_words = 0, upper_slots = 0;
-    vdb::DevBuf<uint32_t> s_patch_idx, s_patch_blk;
+    size_t ovf_used = 0, upper_words = 0, upper_slots = 0, upper_lists_packed = 0; uint64_t entry_at_pack = ~0ull;
+    vdb::DevBuf<uint32_t> s_patch_idx, s_patch_blk, s_delta;
+    // appends to layer-0 lists whose device block is otherwise current: (slot, position in the packed list, neighbour)
+    std::vector<uint32_t> delta_slot, delta_pos, delta_val;
+    void verify_layer0();                                    // VDB_VERIFY_DEVICE=1: device blocks against a fresh pack of the host lists
     size_t l0_edges = 0, upper_edges = 0, device_bytes = 0, l0_edges_acc = 0;
     // per-call scratch (guarded by mu)
     mutable std::mutex mu;
@@ -99,7 +102,9 @@ struct vdb_index {
                       size_t n_layers, const vdb_layer_csr* csr, bool has_entry, uint64_t entry, size_t cur_max);
 
     // device
-    void sync_device();                                      // upload rows / packed graph / tombstones if stale
+    // upload rows / packed graph / tombstones if stale.  for_build: a round of the batched builder may search upper
+    // layers that lack the newest few percent of their nodes (they are re-packed as a whole, which costs O(n))
+    void sync_device(bool for_build = false);
     void pack_layer0_full(); void patch_layer0(); void pack_upper();
     void clean_list(const std::vector<uint32_t>& src, uint32_t self, std::vector<uint32_t>& out);
     static void fill_block(uint32_t* blk, const std::vector<uint32_t>& lst, std::vector<uint32_t>& ovf, size_t ovf_base);
@@ -127,7 +132,7 @@ struct vdb_index {
     uint32_t append_rows(const uint64_t* pids, const float* v, size_t n);
     size_t draw_level();
     struct BuildResult { std::vector<uint32_t> off, nb, cnt; };
-    BuildResult build_search(const std::vector<uint32_t>& slots, uint32_t entry_slot);
+    BuildResult build_search(const std::vector<uint32_t>& slots, uint32_t entry_slot, bool lazy_upper = false);
     void link_point(uint32_t slot, const BuildResult& br, size_t qi);
     uint32_t pick_hash_log2(size_t ef, bool& global) const;
     uint32_t beam_width() const;       // nodes expanded per step of the FAST layer-0 beam (vdb_options.beam_width, VDB_BEAM_WIDTH)

@@ -374,6 +374,22 @@ __global__ void __launch_bounds__(64) patch_blocks_kernel(uint32_t* __restrict__
     adj0[(size_t)idx[blockIdx.x] * ADJ_BLOCK + threadIdx.x] = blocks[(size_t)blockIdx.x * ADJ_BLOCK + threadIdx.x];
 }
 }  // namespace
+namespace {
+__global__ void __launch_bounds__(256) patch_entries_kernel(uint32_t* __restrict__ adj0, const uint32_t* __restrict__ slot, const uint32_t* __restrict__ pos,
+                                                            const uint32_t* __restrict__ val, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t* blk = adj0 + (size_t)slot[i] * ADJ_BLOCK;
+    blk[1 + pos[i]] = val[i];
+    atomicMax(blk, pos[i] + 1u);
+}
+}  // namespace
+void launch_patch_entries(uint32_t* adj0, const uint32_t* slot, const uint32_t* pos, const uint32_t* val, uint32_t n, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(patch_entries_kernel, dim3((n + 255) / 256), dim3(256), 0, st, adj0, slot, pos, val, n);
+    VDB_HIP(hipGetLastError());
+}
+
 void launch_patch_blocks(uint32_t* adj0, const uint32_t* idx, const uint32_t* blocks, uint32_t n, hipStream_t st) {
     if (n == 0) return;
     hipLaunchKernelGGL(patch_blocks_kernel, dim3(n), dim3(64), 0, st, adj0, idx, blocks);

@@ -99,6 +99,8 @@ void launch_exact_knn(const GraphView& g, const float* queries, uint32_t nq, uin
 void launch_patch_blocks(uint32_t* adj0, const uint32_t* idx, const uint32_t* blocks, uint32_t n, hipStream_t s);
 // out_vecs row j <- row slots[j] of the table (stride floats), out_ids[j] <- its PointId.
 void launch_gather_rows(const GraphView& g, const uint32_t* slots, uint32_t n, float* out_vecs, uint64_t* out_ids, hipStream_t s);
+// adj0 block slot[i]: neighbour word 1 + pos[i] <- val[i], degree word <- max(degree, pos[i] + 1): appends to layer-0 lists.
+void launch_patch_entries(uint32_t* adj0, const uint32_t* slot, const uint32_t* pos, const uint32_t* val, uint32_t n, hipStream_t s);
 uint32_t exact_knn_chunks(uint32_t n);
 // FAST exact k-NN: fp32 MFMA candidate pass + strict re-rank (knn_mfma.hip).  scratch holds knn_mfma_scratch_words() dwords.
 bool knn_mfma_supported(const GraphView& g, uint32_t top_k);
