@@ -156,7 +156,7 @@ void vdb_index::pack_layer0_full() {
             h_deg0[s] = (uint32_t)tmp.size(); edges += tmp.size();
         }
     }
-    l0_edges = edges; ovf_used = ovf.size();
+    l0_edges = edges; ovf_used = ovf.size(); ovf_live = ovf.size();
     const size_t n1 = std::max<size_t>(n, 1);
     d_adj0.reserve(n1 * ADJ_BLOCK, stream, false); d_ovf.reserve(std::max<size_t>(ovf.size(), 1), stream, false);
     if (n) VDB_HIP(hipMemcpyAsync(d_adj0.p, adj0.data(), adj0.size() * 4, hipMemcpyHostToDevice, stream));
@@ -197,6 +197,9 @@ void vdb_index::patch_layer0() {
         const std::vector<uint32_t>* lst = list(0, s);
         if (lst) clean_list(*lst, s, tmp); else tmp.clear();
         fill_block(&blocks[idx.size() * ADJ_BLOCK], tmp, ovf, ovf_used);
+        // the overflow run of a hub list is written anew at the end of `ovf`; its old run becomes dead space
+        ovf_live += tmp.size() > ADJ_INLINE ? tmp.size() - ADJ_INLINE : 0;
+        ovf_live -= h_deg0[s] > ADJ_INLINE ? h_deg0[s] - ADJ_INLINE : 0;
         l0_edges += tmp.size(); l0_edges -= h_deg0[s]; h_deg0[s] = (uint32_t)tmp.size();
         idx.push_back(s);
     }
@@ -299,7 +302,8 @@ void vdb_index::sync_device(bool for_build) {
     const size_t n = ids.size();
     if (graph_dirty) {
         // a whole re-pack only when most blocks changed: patching a block costs about as much as packing it
-        const bool full = need_full || d_adj0.cap == 0 || dirty0.size() * 2 > n;
+        const bool full = need_full || d_adj0.cap == 0 || dirty0.size() * 2 > n ||
+                          ovf_used > 8 * ovf_live + (size_t(1) << 22);          // mostly dead overflow runs: pack anew
         if (full) pack_layer0_full(); else patch_layer0();
         bool upper_now = full || upper_dirty;
         if (upper_now && !full && for_build && d_upper_base.cap != 0) {

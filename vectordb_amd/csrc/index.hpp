@@ -71,6 +71,7 @@ struct vdb_index {
     // device, the part of `ovf` in use; upper layers are re-packed as a whole when any of their lists changed
     std::vector<uint32_t> dirty0, h_deg0, clean_stamp; std::vector<uint8_t> dirty0_mark;
     uint32_t clean_epoch = 0; bool upper_dirty = true, need_full = true;
+    size_t ovf_live = 0;                                      // entries of `ovf` that a block still points at
     size_t ovf_used = 0, upper_words = 0, upper_slots = 0, upper_lists_packed = 0; uint64_t entry_at_pack = ~0ull;
     vdb::DevBuf<uint32_t> s_patch_idx, s_patch_blk, s_delta;
     // appends to layer-0 lists whose device block is otherwise current: (slot, position in the packed list, neighbour)
