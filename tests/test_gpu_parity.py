@@ -511,3 +511,49 @@ def test_incremental_device_copy_equals_a_fresh_pack(vdb, monkeypatch):
         rb, nb, sb = b.search_batch(q, k, ef_search=ef, with_stats=True)
         assert np.array_equal(na, nb) and np.array_equal(ra["id"], rb["id"]) and np.array_equal(sa["expanded"], sb["expanded"])
         assert np.array_equal(ra["sort_key"].view(np.uint32), rb["sort_key"].view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_masked_walk_on_the_register_beam(ora, vdb, monkeypatch, metric):
+    """FAST arithmetic, wide filter: the masked walk runs on the register-resident beam with the passing rows in a
+    register list.  Strictly best-first (beam_width = 1) it must return what the LDS-list kernel returns on the same
+    segment (same arithmetic, same order of expansion); at the default width recall against the brute force over
+    the passing rows is no worse; a tiny visited table changes nothing; every result passes and no id repeats."""
+    monkeypatch.setenv("VDB_MASKED_SCAN", "0")                  # keep the walk although half of the rows pass
+    n, d, k, nq = 6000, 32, 10, 300
+    x = data(n, d, 131 + metric, "clustered"); q = data(nq, d, 132, "clustered")
+    if metric != 2:
+        x /= np.linalg.norm(x, axis=1, keepdims=True); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    pay = []
+    for i in range(n):
+        p = vdb.Payload(); p.set("half", vdb.PayloadValue.Int(i % 2)); pay.append(p)
+    f = vdb.Filter.Match("half", vdb.PayloadValue.Int(1))
+
+    def segment(width):
+        seg = vdb.Segment(vdb.HNSWIndex(metric, 16, 64, 16, d, seed=9, arith=vdb.Arith.Fast, filter_mode=vdb.FilterMode.Masked, beam_width=width))
+        ids = seg.insert_batch(x, pay)
+        return seg, ids
+    s1, ids = segment(1)
+    passing = [i for i in range(n) if i % 2 == 1]
+    hb = ora.HNSWIndex(metric, 16, 64, 16, d, seed=9)
+    for i in passing: hb.insert(int(ids[i]), x[i])
+    exact, exact_n = hb.exact_knn_batch(q, k)
+    reg, regn = s1.search_batch(q, k, ef_search=96, filter=f)
+    monkeypatch.setenv("VDB_FORCE_GENERIC", "1")
+    gen, genn = s1.search_batch(q, k, ef_search=96, filter=f)
+    monkeypatch.delenv("VDB_FORCE_GENERIC")
+    assert compare_results(gen, genn, reg, regn, exact=False) <= nq * k // 200
+    s4, _ = segment(0)
+    wide, widen = s4.search_batch(q, k, ef_search=96, filter=f)
+    monkeypatch.setenv("VDB_TAG_LOG2", "7")
+    tiny, tinyn = s4.search_batch(q, k, ef_search=96, filter=f)
+    monkeypatch.delenv("VDB_TAG_LOG2")
+    assert np.array_equal(widen, tinyn) and np.array_equal(wide["id"], tiny["id"]) and np.array_equal(wide["sort_key"].view(np.uint32), tiny["sort_key"].view(np.uint32))
+    assert _recall(wide, widen, exact, exact_n, k) >= _recall(gen, genn, exact, exact_n, k) - 0.005
+    odd = {int(ids[i]) for i in passing}
+    for out, cnt in ((reg, regn), (wide, widen)):
+        assert (cnt == k).all()
+        for i in range(nq):
+            row = out["id"][i][: cnt[i]].tolist()
+            assert len(set(row)) == len(row) and set(row) <= odd
+            assert np.all(np.diff(out["sort_key"][i][: cnt[i]]) >= 0)

@@ -11,7 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=200_000); ap.add_argument("--dim", type=int, default=128)
 ap.add_argument("--queries", type=int, default=2000); ap.add_argument("--k", type=int, default=10)
 ap.add_argument("--ef", type=int, default=128); ap.add_argument("--metric", type=int, default=2)
-ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--steps", type=int, default=3); ap.add_argument("--modes", default="masked,literal")
 args = ap.parse_args()
 import vectordb_amd
 vdb = vectordb_amd.api()
@@ -45,6 +45,7 @@ cases = [
     ("cat == 7 (1 %)", lambda: F.Match("cat", PV.Int(7)), cat == 7),
     ("tier == 3 (10 %)", lambda: F.Match("tier", PV.Int(3)), tier == 3),
     ("tier == 3 and cat < 50 (5 %)", lambda: F.And([F.Match("tier", PV.Int(3)), F.Compare("cat", Op.Lt, PV.Int(50))]), (tier == 3) & (cat < 50)),
+    ("cat < 50 (50 %)", lambda: F.Compare("cat", Op.Lt, PV.Int(50)), cat < 50),
 ]
 
 def ground_truth(mask):
@@ -56,7 +57,7 @@ def ground_truth(mask):
     return [set(rows[t].tolist()) for t in top]
 
 truths = [ground_truth(mask) for _, _, mask in cases]
-for mode in (vdb.FilterMode.Masked, vdb.FilterMode.Literal):
+for mode in [m for m in (vdb.FilterMode.Masked, vdb.FilterMode.Literal) if m.name.lower() in args.modes.split(",")]:
     seg = build(mode)
     for (name, make, mask), truth in zip(cases, truths):
         f = make()

@@ -382,6 +382,7 @@ void vdb_index::run_search(SearchArgs a, size_t nq, hipStream_t s, bool retry_on
     a.tag_log2 = 12;
     while (a.tag_log2 < 15 && ((uint64_t)a.g.n >> (a.tag_log2 + 13)) != 0) ++a.tag_log2;
     if (forced_tags >= 7 && forced_tags <= 15) a.tag_log2 = (uint32_t)forced_tags;      // tests shrink it to force forgetting
+    if (const char* fg = getenv("VDB_FORCE_GENERIC")) { if (atoi(fg) != 0) a.force_generic = 1; }   // tests: the LDS-list kernel for every mode
     // one spill table per possibly resident wavefront (256 CUs x 16), 2^15 ids each
     a.spill_log2 = 15;
     a.spill_tables = 4096;

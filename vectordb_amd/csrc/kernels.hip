@@ -18,6 +18,7 @@ size_t search_lds_bytes(const SearchArgs& a) {
     const size_t staging = (nc ? 256 : 64) * 8;      // cand + craw
     const size_t tags = nc ? ((size_t)2 << a.tag_log2) : 0;   // 16-bit visited table
     if (nc && a.mode == MODE_SEARCH) return ((std::max(std::max(nc * 512, row), staging) + 15) & ~(size_t)15) + tags;   // one shared staging area
+    if (nc && a.mode == MODE_MASKED) return ((std::max(std::max((nc + 1) * 512, row), staging) + 15) & ~(size_t)15) + tags;   // + the passing list
     return ef_cap * 16 + (a.mode == MODE_MASKED ? ef_cap * 16 : 0) + nc * 512 + tags + staging + row + hash;
 }
 

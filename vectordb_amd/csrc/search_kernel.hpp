@@ -399,7 +399,7 @@ struct Searcher {
     // width == 1 is the reference's strictly best-first order.  Euclidean keys are squared
     // distances until the list is handed over in R (LDS).  The visited set is the TagSet in LDS,
     // which forgets ids instead of filling up (see TagSet): no query can outgrow it.
-    __device__ __forceinline__ void beam_reg(uint32_t entry, uint32_t ef, uint32_t width) {
+    template <bool MASKED> __device__ __forceinline__ void beam_reg(uint32_t entry, uint32_t ef, uint32_t width) {
         constexpr int EMAX = 4;
         const int lane = lane_id();
         const float INF = __int_as_float(0x7f800000);
@@ -411,6 +411,28 @@ struct Searcher {
 #pragma unroll
         for (int c = 0; c < NCC; ++c) { rk[c] = INF; rv[c] = FLAG_EXPANDED; }
         const uint32_t cap = ef;
+        // MASKED: the best filter-passing rows among everything scored, ascending, entry `lane` in this lane;
+        // the walk itself does not depend on it (hnsw.rs has no such mode: extension of the masked filter mode)
+        float pk = INF; uint32_t pv = 0, pn = 0; float p_worst = INF;
+        const uint32_t pcap = a.top_k < (uint32_t)WAVE ? (a.top_k ? a.top_k : 1u) : (uint32_t)WAVE;
+        auto offer_passing = [&](bool have, float kj, uint32_t sj) {
+            bool ok = have && (pn < pcap || kj < p_worst);
+            if (ok && a.pass_bits) ok = bit_test(a.pass_bits, sj);
+            uint64_t om = ballot(ok);
+            while (om) {
+                const int l = __ffsll((unsigned long long)om) - 1; om &= om - 1;
+                const float k = readlane_f(kj, l); const uint32_t s = readlane_u(sj, l);
+                if (pn >= pcap && !(k < p_worst)) continue;
+                if (ballot((uint32_t)lane < pn && pk == k && pv == s)) continue;          // scored twice (forgotten by the visited set)
+                const uint32_t pos = popc64(ballot((uint32_t)lane < pn && pk <= k));      // equal keys: earlier arrivals first
+                const float uk = __shfl_up(pk, 1); const uint32_t uv = (uint32_t)__shfl_up((int)pv, 1);
+                if ((uint32_t)lane > pos) { pk = uk; pv = uv; }
+                if ((uint32_t)lane == pos) { pk = k; pv = s; }
+                pn = pn < pcap ? pn + 1 : pcap;
+                if ((uint32_t)lane >= pn) { pk = INF; pv = 0; }
+                p_worst = pn >= pcap ? readlane_f(pk, (int)pcap - 1) : INF;
+            }
+        };
         uint32_t n = 0;
         bool forgot = false;             // the visited set replaced an id: candidates are checked against the list from here on
         float worst = INF;
@@ -430,6 +452,7 @@ struct Searcher {
             if (lane == 0) { rk[0] = k0; rv[0] = start; }
             n = 1;
             if (cap == 1) worst = k0;
+            if (MASKED) offer_passing(lane == 0 && !is_deleted(start), k0, start);
         }
         wave_sync();
 #ifdef VDB_TIMING
@@ -579,6 +602,7 @@ struct Searcher {
                     float kj = kjr[0]; uint32_t sj = sjr[0];
 #pragma unroll
                     for (int r = 1; r < CAND_CAP / WAVE; ++r) if (base == r * WAVE) { kj = kjr[r]; sj = sjr[r]; }
+                    if (MASKED) offer_passing(have, kj, sj);
                     bool pass = have && (n < cap || kj < worst);                  // hnsw.rs:486
                     uint64_t pm = ballot(pass);
                     if (pm == 0) continue;
@@ -653,6 +677,10 @@ struct Searcher {
             if (i < n) { R.key[i] = (metric() == VDB_EUCLIDEAN) ? __builtin_sqrtf(rk[c]) : rk[c]; R.val[i] = rv[c]; }
         }
         R.n = n; R.cap = cap;
+        if (MASKED) {
+            if ((uint32_t)lane < pn) { P.key[lane] = (metric() == VDB_EUCLIDEAN) ? __builtin_sqrtf(pk) : pk; P.val[lane] = pv; }
+            P.n = pn; P.cap = pcap;
+        }
         wave_sync();
     }
 
@@ -754,13 +782,18 @@ struct Searcher {
         // ---- carve LDS (every offset a multiple of 16 bytes) ----
         const uint32_t ef_cap = (a.ef + 63u) & ~63u;
         size_t off = 0;
-        if (NC > 0 && MODE == MODE_SEARCH) {
+        if (NC > 0 && (MODE == MODE_SEARCH || MODE == MODE_MASKED)) {
             // register-resident list: LDS only stages permutations, the query (until it is in
             // registers) and the final list, all in one area
             // (candidate ids + scores, then the permutation of the merge, which has read them into registers)
             size_t area = (size_t)CAND_CAP * 8;
             if ((size_t)NCC * WAVE * 8 > area) area = (size_t)NCC * WAVE * 8;
             if ((size_t)gv.stride * 4 > area) area = (size_t)gv.stride * 4;
+            if (MODE == MODE_MASKED) {                     // the passing list is handed over behind the result list
+                if ((size_t)(NCC + 1) * WAVE * 8 > area) area = (size_t)(NCC + 1) * WAVE * 8;
+                P.key = reinterpret_cast<float*>(smem + (size_t)NCC * WAVE * 8); P.val = reinterpret_cast<uint32_t*>(P.key + WAVE);
+                P.key2 = nullptr; P.val2 = nullptr;
+            }
             perm = reinterpret_cast<uint2*>(smem);
             qlds = reinterpret_cast<float*>(smem);
             R.key = reinterpret_cast<float*>(smem); R.val = reinterpret_cast<uint32_t*>(smem) + NCC * WAVE;
@@ -828,7 +861,7 @@ struct Searcher {
             } else
             for (uint32_t l = a.max_level; l > lvl; --l) cur = greedy(cur, l);          // hnsw.rs:169-173
             for (int l = (int)lvl; l >= 0; --l) {                                       // hnsw.rs:175-199
-                if (l == 0) { if (NC > 0) beam_reg(cur, a.ef, a.beam_width); else beam<false, true>(cur, 0, a.ef); }
+                if (l == 0) { if (NC > 0) beam_reg<false>(cur, a.ef, a.beam_width); else beam<false, true>(cur, 0, a.ef); }
                 else beam<false, false>(cur, (uint32_t)l, a.ef);
                 if (flags & QF_HASH_OVERFLOW) break;
                 const uint32_t cnt = R.n < a.m ? R.n : a.m;
@@ -846,9 +879,12 @@ struct Searcher {
                 for (uint32_t l = a.max_level; l >= 1; --l) cur = greedy_fused(cur, ref, l, kc, hc);
             } else
             for (uint32_t l = a.max_level; l >= 1; --l) cur = greedy(cur, l);           // hnsw.rs:538-541
-            if (MODE == MODE_MASKED) { beam<true, true>(cur, 0, a.ef); if (!(flags & QF_HASH_OVERFLOW)) emit(q, P, false); }
+            if (MODE == MODE_MASKED) {
+                if (NC > 0) beam_reg<true>(cur, a.ef, a.beam_width); else beam<true, true>(cur, 0, a.ef);
+                if (!(flags & QF_HASH_OVERFLOW)) emit(q, P, false);
+            }
             else {
-                if (NC > 0) beam_reg(cur, a.ef, a.beam_width); else beam<false, true>(cur, 0, a.ef);
+                if (NC > 0) beam_reg<false>(cur, a.ef, a.beam_width); else beam<false, true>(cur, 0, a.ef);
                 if (!(flags & QF_HASH_OVERFLOW)) emit(q, R, false);
             }
         }
@@ -892,7 +928,7 @@ void launch_search_shape(const SearchArgs& a, size_t lds, hipStream_t st) {
 }
 template <int MODE, int METRIC>
 void launch_search_fast(const SearchArgs& a, size_t lds, hipStream_t st) {
-    if (MODE == MODE_SEARCH || MODE == MODE_BUILD) {
+    if (MODE == MODE_SEARCH || MODE == MODE_BUILD || MODE == MODE_MASKED) {
         switch (reg_list_chunks(a)) {
             case 1: launch_search_shape<MODE, METRIC, 1>(a, lds, st); return;
             case 2: launch_search_shape<MODE, METRIC, 2>(a, lds, st); return;
