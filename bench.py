@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """bench.py — queries/sec at recall@10 >= 0.95 on the SIFT1M-shape synthetic set (1M x 128 fp32, L2,
-10k-query batch), the hot path of BASELINE.json measured through the C ABI.
+10k-query batch): the segment search path measured through the C ABI.
 
 One "step" = one pass of the batched HNSW search (greedy descent + layer-0 ef-beam, one wavefront per
 query) over the whole 10k-query batch, queries and results resident in HBM.  The graph is built on
