@@ -1,5 +1,6 @@
 // Segment (src/segment/segment.rs) over the device-resident index: id assignment, payload
 // bookkeeping, tombstones and purge on the host; every distance on the GPU.
+#include <algorithm>
 #include <cstring>
 
 #include "index.hpp"
@@ -190,15 +191,23 @@ void vdb_segment::filter_aware_edges_batch(const std::vector<uint64_t>& pids, co
                 if (live.size() <= amount + 1) {
                     for (uint32_t s : live) if (s != self) { qs.push_back(self); ss.push_back(s); }
                 } else {
-                    // amount + 1 distinct positions, so that dropping `self` (if drawn) still leaves `amount`
-                    std::set<size_t> chosen;
+                    // amount + 1 distinct positions, so that dropping `self` (if drawn) still leaves `amount`;
+                    // membership in a 256-slot open-addressing table on the stack, positions then in ascending order
                     const size_t N = live.size(), want = amount + 1;
+                    size_t table[256]; std::fill(table, table + 256, SIZE_MAX);
+                    size_t chosen[amount + 1]; size_t nc = 0;
+                    auto add = [&](size_t v) -> bool {
+                        size_t hsh = (v * 0x9E3779B97F4A7C15ull) >> 56;
+                        while (table[hsh] != SIZE_MAX) { if (table[hsh] == v) return false; hsh = (hsh + 1) & 255; }
+                        table[hsh] = v; chosen[nc++] = v; return true;
+                    };
                     for (size_t r = N - want; r < N; ++r) {
                         const size_t t2 = (size_t)(rng_draw(h.opts.seed, 2, h.sample_draws++) % (r + 1));
-                        if (!chosen.insert(t2).second) chosen.insert(r);
+                        if (!add(t2)) add(r);
                     }
+                    std::sort(chosen, chosen + nc);
                     size_t taken = 0;
-                    for (size_t pos : chosen) { if (live[pos] == self || taken == amount) continue; qs.push_back(self); ss.push_back(live[pos]); ++taken; }
+                    for (size_t c = 0; c < nc; ++c) { const size_t pos = chosen[c]; if (live[pos] == self || taken == amount) continue; qs.push_back(self); ss.push_back(live[pos]); ++taken; }
                 }
             }
             j.count = qs.size() - j.first;
@@ -212,10 +221,13 @@ void vdb_segment::filter_aware_edges_batch(const std::vector<uint64_t>& pids, co
     const size_t ef = h.ef;
     h.search_from_rows(rows, h.slot_of.at(*h.entry_point), ef, found, found_n);
 
-    struct Scored { uint32_t slot; float raw; };
-    auto sort_raw = [&](std::vector<Scored>& v) {                                  // hnsw.rs:250-256 / :291-297 (stable)
-        if (h.metric == VDB_DOT) std::stable_sort(v.begin(), v.end(), [](const Scored& a, const Scored& b) { return a.raw > b.raw; });
-        else std::stable_sort(v.begin(), v.end(), [](const Scored& a, const Scored& b) { return a.raw < b.raw; });
+    struct Scored { uint32_t slot; float raw; uint32_t at; };
+    // the first `keep` entries of the stable sort of hnsw.rs:250-256 / :291-297: ties keep their arrival order
+    auto best_first = [&](std::vector<Scored>& v, size_t keep) {
+        for (size_t i = 0; i < v.size(); ++i) v[i].at = (uint32_t)i;
+        keep = std::min(keep, v.size());
+        if (h.metric == VDB_DOT) std::partial_sort(v.begin(), v.begin() + keep, v.end(), [](const Scored& a, const Scored& b) { return a.raw > b.raw || (a.raw == b.raw && a.at < b.at); });
+        else std::partial_sort(v.begin(), v.begin() + keep, v.end(), [](const Scored& a, const Scored& b) { return a.raw < b.raw || (a.raw == b.raw && a.at < b.at); });
     };
     size_t jb = 0;
     for (size_t t = 0; t < pts.size(); ++t) {
@@ -228,14 +240,14 @@ void vdb_segment::filter_aware_edges_batch(const std::vector<uint64_t>& pids, co
             const Job& j = jobs[jb];
             if (payload_index.query_exact(j.key, *j.value)) {
                 std::vector<Scored> scored;
-                for (size_t k = 0; k < j.count; ++k) scored.push_back({ss[j.first + k], raw[j.first + k]});
-                sort_raw(scored);
+                for (size_t k = 0; k < j.count; ++k) scored.push_back({ss[j.first + k], raw[j.first + k], 0});
+                best_first(scored, m);
                 for (size_t k = 0; k < scored.size() && k < m; ++k) extra.insert(h.ids[scored[k].slot]);
                 if (extra.size() >= m) { done = true; continue; }
             }
             std::vector<Scored> candidates;
-            for (uint32_t k = 0; k < found_n[t]; ++k) { const vdb_scored_point& sp = found[t * ef + k]; candidates.push_back({h.slot_of.at(sp.id), sp.raw_score}); }
-            sort_raw(candidates);
+            for (uint32_t k = 0; k < found_n[t]; ++k) { const vdb_scored_point& sp = found[t * ef + k]; candidates.push_back({h.slot_of.at(sp.id), sp.raw_score, 0}); }
+            best_first(candidates, candidates.size());     // every entry may be needed: only same-value rows count
             size_t taken = 0;
             for (const Scored& c : candidates) {
                 if (taken >= m) break;
