@@ -25,7 +25,9 @@ hb.insert_batch(ids, base)
 tb = time.time() - t0
 t0 = time.time()
 ho = ora.HNSWIndex(M, 16, 64, 16, d, seed=7)
-ho.insert_batch(ids, base)
+for lo in range(0, n, 50_000):                      # in pieces, with a progress line: a long silent run looks hung
+    ho.insert_batch(ids[lo:lo + 50_000], base[lo:lo + 50_000])
+    print(f"  oracle inserted {min(n, lo + 50_000)} ({time.time() - t0:.0f}s)", flush=True)
 to = time.time() - t0
 hs = vdb.HNSWIndex(M, 16, 64, 16, d, seed=7)
 hs.import_graph(ho.export_graph())
