@@ -31,6 +31,18 @@ vdb_index::vdb_index(vdb_metric metric_, size_t m_, size_t ef_, size_t cap_, siz
 
 vdb_index::~vdb_index() {
     if (stream) { (void)hipSetDevice(opts.device); (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+    if (h_pin) (void)hipHostFree(h_pin);
+}
+
+void* vdb_index::pinned(size_t bytes) const {
+    if (bytes > h_pin_bytes) {
+        if (h_pin) VDB_HIP(hipHostFree(h_pin));
+        h_pin = nullptr; h_pin_bytes = 0;
+        const size_t want = std::max<size_t>(bytes, 64 * 1024);
+        VDB_HIP(hipHostMalloc(&h_pin, want, hipHostMallocDefault));
+        h_pin_bytes = want;
+    }
+    return h_pin;
 }
 
 void vdb_index::use_device() const { VDB_HIP(hipSetDevice(opts.device)); }
@@ -445,7 +457,12 @@ void vdb_index::search_batch(const float* q, size_t nq, size_t top_k, size_t ef_
     sync_device();
     s_q.reserve(nq * dim, stream, false); s_out.reserve(nq * top_k, stream, false);
     s_n.reserve(nq, stream, false); s_stats.reserve(nq, stream, false);
-    VDB_HIP(hipMemcpyAsync(s_q.p, q, nq * dim * sizeof(float), hipMemcpyHostToDevice, stream));
+    // small batches go through pinned host memory: copies from and to pageable memory cost more than the search of one query
+    const size_t b_q = nq * dim * sizeof(float), b_out = nq * top_k * sizeof(vdb_scored_point), b_n = nq * sizeof(uint32_t), b_st = nq * sizeof(vdb_query_stats);
+    const bool small = b_q + b_out + b_n + b_st <= (size_t(1) << 20);
+    char* pin = small ? static_cast<char*>(pinned(b_q + b_out + b_n + b_st)) : nullptr;
+    if (small) { std::memcpy(pin, q, b_q); VDB_HIP(hipMemcpyAsync(s_q.p, pin, b_q, hipMemcpyHostToDevice, stream)); }
+    else VDB_HIP(hipMemcpyAsync(s_q.p, q, nq * dim * sizeof(float), hipMemcpyHostToDevice, stream));
     SearchArgs a{};
     a.g = view(); a.mode = fa.mode; a.arith = opts.arith; a.queries = s_q.p; a.nq = (uint32_t)nq;
     a.entry = fa.entry_slot != NONE32 ? fa.entry_slot : slot_of.at(*entry_point);
@@ -467,10 +484,18 @@ void vdb_index::search_batch(const float* q, size_t nq, size_t top_k, size_t ef_
     }
     run_search(a, nq, stream, true, s_q.p);
     std::vector<vdb_query_stats> st(nq);
-    VDB_HIP(hipMemcpyAsync(out, s_out.p, nq * top_k * sizeof(vdb_scored_point), hipMemcpyDeviceToHost, stream));
-    VDB_HIP(hipMemcpyAsync(out_n, s_n.p, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    VDB_HIP(hipMemcpyAsync(st.data(), s_stats.p, nq * sizeof(vdb_query_stats), hipMemcpyDeviceToHost, stream));
-    VDB_HIP(hipStreamSynchronize(stream));
+    if (small) {
+        VDB_HIP(hipMemcpyAsync(pin + b_q, s_out.p, b_out, hipMemcpyDeviceToHost, stream));
+        VDB_HIP(hipMemcpyAsync(pin + b_q + b_out, s_n.p, b_n, hipMemcpyDeviceToHost, stream));
+        VDB_HIP(hipMemcpyAsync(pin + b_q + b_out + b_n, s_stats.p, b_st, hipMemcpyDeviceToHost, stream));
+        VDB_HIP(hipStreamSynchronize(stream));
+        std::memcpy(out, pin + b_q, b_out); std::memcpy(out_n, pin + b_q + b_out, b_n); std::memcpy(st.data(), pin + b_q + b_out + b_n, b_st);
+    } else {
+        VDB_HIP(hipMemcpyAsync(out, s_out.p, nq * top_k * sizeof(vdb_scored_point), hipMemcpyDeviceToHost, stream));
+        VDB_HIP(hipMemcpyAsync(out_n, s_n.p, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        VDB_HIP(hipMemcpyAsync(st.data(), s_stats.p, nq * sizeof(vdb_query_stats), hipMemcpyDeviceToHost, stream));
+        VDB_HIP(hipStreamSynchronize(stream));
+    }
     for (size_t i = 0; i < nq; ++i) {
         if (st[i].flags & QF_CAND_OVERFLOW)
             throw Failure(err_device("literal filtered search: the candidate queue of query " + std::to_string(i) + " outgrew " + std::to_string(a.cand_cap) +

@@ -80,6 +80,8 @@ struct vdb_index {
     size_t l0_edges = 0, upper_edges = 0, device_bytes = 0, l0_edges_acc = 0;
     // per-call scratch (guarded by mu)
     mutable std::mutex mu;
+    mutable void* h_pin = nullptr; mutable size_t h_pin_bytes = 0;     // pinned staging of small search batches (one query per call is the reference's shape)
+    void* pinned(size_t bytes) const;
     mutable vdb::DevBuf<float> s_q, s_raw, s_sub_vecs; mutable vdb::DevBuf<uint64_t> s_sub_ids; mutable vdb::DevBuf<vdb_scored_point> s_out, s_knn, s_cand;
     mutable vdb::DevBuf<uint32_t> s_knn_words, s_n, s_slots, s_qslots, s_lvl, s_off, s_nb, s_nbc, s_hash, s_spill; mutable vdb::DevBuf<vdb_query_stats> s_stats;
     mutable std::map<hipStream_t, vdb::DevBuf<vdb_query_stats>> s_stats_by_stream;
