@@ -18,33 +18,6 @@ __global__ void __launch_bounds__(256) mfma_loop(float* out, int iters, float a0
     for (int t = 0; t < 4; ++t) for (int v = 0; v < 16; ++v) s += acc[t][v];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
-// Second experiment: blocks alternate between the MFMA loop and a plain VALU loop (independent FMAs), so that every
-// SIMD holds one wave of each kind: how much of the matrix rate survives next to ordinary vector work?
-__global__ void __launch_bounds__(256) mixed_loop(float* out, int iters, float a0, float b0, int valu_per_mfma) {
-    if ((blockIdx.x / 256) & 1) {         // the second block of every CU (blocks are dealt round-robin over XCDs and CUs)
-        float x[8];
-        for (int i = 0; i < 8; ++i) x[i] = a0 + i + threadIdx.x;
-        for (int i = 0; i < iters * 32; ++i)
-            for (int r = 0; r < valu_per_mfma; ++r)
-#pragma unroll
-                for (int u = 0; u < 8; ++u) x[u] = __builtin_fmaf(x[u], b0, 1.0f);
-        float s = 0.f; for (int i = 0; i < 8; ++i) s += x[i];
-        out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-        return;
-    }
-    floatx16 acc[4];
-    for (int t = 0; t < 4; ++t) for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
-    float a = a0 + threadIdx.x, b = b0;
-    for (int i = 0; i < iters; ++i) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
-    }
-    float s = 0.f;
-    for (int t = 0; t < 4; ++t) for (int v = 0; v < 16; ++v) s += acc[t][v];
-    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-}
 int main() {
     float* d; hipMalloc(&d, 4096 * 256 * 4);
     for (int wpb : {1, 2}) {
@@ -55,15 +28,6 @@ int main() {
         float ms = 0; hipEventElapsedTime(&ms, e0, e1);
         const double flop = (double)blocks * 4 /*waves*/ * iters * 32 /*mfma*/ * 4096.0;
         printf("%d block(s) of 4 waves per CU: %.1f ms, %.1f TFLOP/s\n", wpb, ms, flop / ms / 1e9);
-    }
-    for (int vpm : {0, 1, 2, 4}) {             // vpm x 8 VALU instructions per MFMA of the neighbouring wave
-        const int blocks = 512, iters = 20000;
-        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        mixed_loop<<<blocks, 256>>>(d, 100, 1.f, 2.f, vpm); hipDeviceSynchronize();
-        hipEventRecord(e0); mixed_loop<<<blocks, 256>>>(d, iters, 1.f, 2.f, vpm); hipEventRecord(e1); hipEventSynchronize(e1);
-        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-        const double flop = (double)(blocks / 2) * 4 * iters * 32 * 4096.0;
-        printf("MFMA waves next to VALU waves issuing %d vector instructions per MFMA: %.1f ms, %.1f TFLOP/s of MFMA\n", vpm * 8, ms, flop / ms / 1e9);
     }
     return 0;
 }
