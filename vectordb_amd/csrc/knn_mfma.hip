@@ -422,50 +422,63 @@ __global__ void __launch_bounds__(64) knn_rerank_kernel(GraphView gv, const floa
     if (lane == 0) out_n[q] = L.n;
 }
 
+// Blocks of one launch do equal work, so the launch lasts ceil(blocks / resident blocks) rounds: the base set is cut
+// into the number of chunks that wastes least of the last round (more chunks also mean more candidates to re-rank).
+inline uint32_t pick_chunks(uint32_t n, uint32_t nq, uint32_t resident) {
+    const uint32_t qblocks = (nq + MQ - 1) / MQ;
+    const uint32_t cmax = std::max<uint32_t>(1, std::min<uint32_t>(64, n / 4096));
+    uint32_t best = 1; double best_cost = 1e30;
+    for (uint32_t c = 1; c <= cmax; ++c) {
+        const uint32_t rounds = (c * qblocks + resident - 1) / resident;
+        const double cost = (double)rounds / c + 0.0008 * c;
+        if (cost < best_cost) { best_cost = cost; best = c; }
+    }
+    return best;
+}
+template <class Kernel>
+uint32_t resident_blocks(Kernel kernel, size_t lds) {
+    int dev = 0, cus = 256, per_cu = 1;
+    VDB_HIP(hipGetDevice(&dev));
+    VDB_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    VDB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds));
+    return (uint32_t)std::max(1, cus) * (uint32_t)std::max(1, per_cu);
+}
 template <int KH, int KP>
-void launch_mfma(const GraphView& g, const float* queries, uint32_t nq, const float* scale, const float* bias, uint32_t* slots,
-                 uint32_t n_chunks, hipStream_t st) {
+uint32_t launch_mfma(const GraphView& g, const float* queries, uint32_t nq, const float* scale, const float* bias, uint32_t* slots, hipStream_t st) {
     constexpr int K = 2 * KH;
     const size_t lds = (size_t)MT * (K + 4) * 4 + 2 * MT * 4 + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8;
+    const uint32_t n_chunks = pick_chunks(g.n, nq, resident_blocks(knn_mfma_kernel<KH, KP>, lds));
     hipLaunchKernelGGL((knn_mfma_kernel<KH, KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, queries, nq, scale, bias, slots, n_chunks);
+    return n_chunks;
 }
 template <int KP>
-void launch_mfma_any(const GraphView& g, const float* queries, uint32_t nq, const float* scale, const float* bias, uint32_t* slots,
-                     uint32_t n_chunks, hipStream_t st) {
-    if (g.stride <= 64) launch_mfma<32, KP>(g, queries, nq, scale, bias, slots, n_chunks, st);
-    else if (g.stride <= 128) launch_mfma<64, KP>(g, queries, nq, scale, bias, slots, n_chunks, st);
-    else if (g.stride <= 256) launch_mfma<128, KP>(g, queries, nq, scale, bias, slots, n_chunks, st);
-    else {
-        const size_t lds = (size_t)2 * LT * LDK * 4 + 2 * LT * 4 + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8;
-        hipLaunchKernelGGL((knn_mfma_long_kernel<KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, queries, nq, scale, bias, slots, n_chunks);
-    }
+uint32_t launch_mfma_any(const GraphView& g, const float* queries, uint32_t nq, const float* scale, const float* bias, uint32_t* slots, hipStream_t st) {
+    if (g.stride <= 64) return launch_mfma<32, KP>(g, queries, nq, scale, bias, slots, st);
+    if (g.stride <= 128) return launch_mfma<64, KP>(g, queries, nq, scale, bias, slots, st);
+    if (g.stride <= 256) return launch_mfma<128, KP>(g, queries, nq, scale, bias, slots, st);
+    const size_t lds = (size_t)2 * LT * LDK * 4 + 2 * LT * 4 + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8;
+    const uint32_t n_chunks = pick_chunks(g.n, nq, resident_blocks(knn_mfma_long_kernel<KP>, lds));
+    hipLaunchKernelGGL((knn_mfma_long_kernel<KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, queries, nq, scale, bias, slots, n_chunks);
+    return n_chunks;
 }
 inline uint32_t knn_kp(uint32_t top_k) { return top_k + 4 <= 16 ? 16u : 32u; }
 
 }  // namespace
 
 bool knn_mfma_supported(const GraphView& g, uint32_t top_k) { return top_k >= 1 && top_k + 4 <= 32 && g.stride <= MAX_DIM && g.n > 0; }
-uint32_t knn_mfma_chunks(uint32_t n, uint32_t nq) {
-    // enough blocks to fill 256 CUs several times over, chunks of at least 4096 rows
-    const uint32_t qblocks = (nq + MQ - 1) / MQ;
-    uint32_t c = (2048 + qblocks - 1) / qblocks;
-    c = std::min<uint32_t>(c, std::max<uint32_t>(1, n / 4096));
-    return std::max<uint32_t>(1, std::min<uint32_t>(c, 64));
-}
-size_t knn_mfma_scratch_words(uint32_t n, uint32_t nq) { return 2 * (size_t)n + (size_t)nq * knn_mfma_chunks(n, nq) * 32; }
+// room for the largest chunk count and candidate width the launch may pick
+size_t knn_mfma_scratch_words(uint32_t n, uint32_t nq) { return 2 * (size_t)n + (size_t)nq * std::max<uint32_t>(1, std::min<uint32_t>(64, n / 4096)) * 32; }
 
 // scratch: knn_mfma_scratch_words() dwords = [scale n][bias n][candidate slots]
 void launch_exact_knn_mfma(const GraphView& g, const float* queries, uint32_t nq, uint32_t top_k, vdb_scored_point* out, uint32_t* out_n,
                            uint32_t* scratch, hipStream_t st) {
     if (nq == 0) return;
-    const uint32_t n_chunks = knn_mfma_chunks(g.n, nq);
     float* scale = reinterpret_cast<float*>(scratch); float* bias = scale + g.n;
     uint32_t* slots = scratch + 2 * (size_t)g.n;
     hipLaunchKernelGGL(knn_prepare_kernel, dim3((g.n + 31) / 32), dim3(256), 0, st, g, scale, bias);
     VDB_HIP(hipGetLastError());
     const uint32_t kp = knn_kp(top_k);
-    if (kp == 16) launch_mfma_any<16>(g, queries, nq, scale, bias, slots, n_chunks, st);
-    else launch_mfma_any<32>(g, queries, nq, scale, bias, slots, n_chunks, st);
+    const uint32_t n_chunks = kp == 16 ? launch_mfma_any<16>(g, queries, nq, scale, bias, slots, st) : launch_mfma_any<32>(g, queries, nq, scale, bias, slots, st);
     VDB_HIP(hipGetLastError());
     const size_t lds = (size_t)g.stride * 4 + (size_t)top_k * 16;
     hipLaunchKernelGGL(knn_rerank_kernel, dim3(nq), dim3(64), lds, st, g, queries, top_k, slots, n_chunks * kp, out, out_n);
