@@ -90,10 +90,11 @@ uint32_t vdb_index::append_rows(const uint64_t* pids, const float* v, size_t n) 
     const uint32_t first = (uint32_t)ids.size();
     const size_t total = ids.size() + n;
     if (total >= 0x7FFFFFFFull) throw Failure(err_arg("more than 2^31 points in one index"));
-    d_vecs.reserve(total * stride, stream);
+    d_vecs.reserve(total * stride, stream); d_ids.reserve(total, stream);
     std::vector<float> padded(n * stride, 0.f);
     for (size_t i = 0; i < n; ++i) std::memcpy(&padded[i * stride], v + i * dim, dim * sizeof(float));
     VDB_HIP(hipMemcpyAsync(d_vecs.p + (size_t)first * stride, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    VDB_HIP(hipMemcpyAsync(d_ids.p + first, pids, n * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
     if (metric == VDB_COSINE) {
         launch_normalize_rows(d_vecs.p, stride, (uint32_t)dim, first, (uint32_t)n, stream);
         VDB_HIP(hipMemcpyAsync(padded.data(), d_vecs.p + (size_t)first * stride, padded.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
@@ -101,9 +102,6 @@ uint32_t vdb_index::append_rows(const uint64_t* pids, const float* v, size_t n) 
     VDB_HIP(hipStreamSynchronize(stream));
     hvecs.resize(total * dim);
     for (size_t i = 0; i < n; ++i) std::memcpy(&hvecs[(first + i) * dim], &padded[i * stride], dim * sizeof(float));
-    d_ids.reserve(total, stream);
-    VDB_HIP(hipMemcpyAsync(d_ids.p + first, pids, n * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
-    VDB_HIP(hipStreamSynchronize(stream));
     for (size_t i = 0; i < n; ++i) {
         const uint32_t s = first + (uint32_t)i;
         ids.push_back(pids[i]); slot_of[pids[i]] = s; deleted.push_back(0); live.insert(pids[i]);
@@ -183,17 +181,6 @@ void vdb_index::patch_layer0() {
     const size_t n = ids.size();
     d_adj0.reserve(std::max<size_t>(n, 1) * ADJ_BLOCK, stream, true);
     h_deg0.resize(n, 0);
-    if (!delta_slot.empty()) {
-        // appended entries first; a list that was also edited some other way is re-packed below as a whole
-        const size_t nd = delta_slot.size();
-        s_delta.reserve(3 * nd, stream, false);
-        VDB_HIP(hipMemcpyAsync(s_delta.p, delta_slot.data(), nd * 4, hipMemcpyHostToDevice, stream));
-        VDB_HIP(hipMemcpyAsync(s_delta.p + nd, delta_pos.data(), nd * 4, hipMemcpyHostToDevice, stream));
-        VDB_HIP(hipMemcpyAsync(s_delta.p + 2 * nd, delta_val.data(), nd * 4, hipMemcpyHostToDevice, stream));
-        launch_patch_entries(d_adj0.p, s_delta.p, s_delta.p + nd, s_delta.p + 2 * nd, (uint32_t)nd, stream);
-        VDB_HIP(hipStreamSynchronize(stream));             // the host vectors are reused
-        delta_slot.clear(); delta_pos.clear(); delta_val.clear();
-    }
     std::vector<uint32_t> idx, blocks(dirty0.size() * ADJ_BLOCK), ovf, tmp;
     idx.reserve(dirty0.size());
     const HostLayer* L0 = layers.empty() ? nullptr : &layers[0];
@@ -220,13 +207,23 @@ void vdb_index::patch_layer0() {
         VDB_HIP(hipMemcpyAsync(d_ovf.p + ovf_used, ovf.data(), ovf.size() * 4, hipMemcpyHostToDevice, stream));
         ovf_used += ovf.size();
     }
-    if (!idx.empty()) {
-        s_patch_idx.reserve(idx.size(), stream, false); s_patch_blk.reserve(blocks.size(), stream, false);
-        VDB_HIP(hipMemcpyAsync(s_patch_idx.p, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, stream));
-        VDB_HIP(hipMemcpyAsync(s_patch_blk.p, blocks.data(), blocks.size() * 4, hipMemcpyHostToDevice, stream));
-        launch_patch_blocks(d_adj0.p, s_patch_idx.p, s_patch_blk.p, (uint32_t)idx.size(), stream);
+    // one upload for both kinds of patch (page-locked when small: a single insert pays no blocking copy); appended
+    // entries go first, a list that was also edited some other way is then re-packed as a whole
+    const size_t nd = delta_slot.size(), words = 3 * nd + idx.size() + blocks.size();
+    if (words) {
+        std::vector<uint32_t> pageable;
+        uint32_t* h;
+        if (words * 4 <= (size_t(256) << 10)) h = static_cast<uint32_t*>(pinned(words * 4));
+        else { pageable.resize(words); h = pageable.data(); }
+        std::memcpy(h, delta_slot.data(), nd * 4); std::memcpy(h + nd, delta_pos.data(), nd * 4); std::memcpy(h + 2 * nd, delta_val.data(), nd * 4);
+        std::memcpy(h + 3 * nd, idx.data(), idx.size() * 4); std::memcpy(h + 3 * nd + idx.size(), blocks.data(), blocks.size() * 4);
+        s_delta.reserve(words, stream, false);
+        VDB_HIP(hipMemcpyAsync(s_delta.p, h, words * 4, hipMemcpyHostToDevice, stream));
+        if (nd) launch_patch_entries(d_adj0.p, s_delta.p, s_delta.p + nd, s_delta.p + 2 * nd, (uint32_t)nd, stream);
+        if (!idx.empty()) launch_patch_blocks(d_adj0.p, s_delta.p + 3 * nd, s_delta.p + 3 * nd + idx.size(), (uint32_t)idx.size(), stream);
     }
     VDB_HIP(hipStreamSynchronize(stream));
+    delta_slot.clear(); delta_pos.clear(); delta_val.clear();
 }
 
 // Diagnostic (VDB_VERIFY_DEVICE=1): every layer-0 block on the device must describe the packed form of the
@@ -335,10 +332,9 @@ void vdb_index::sync_device(bool for_build) {
         }
         if (!upper_now && upper_slots != n) {    // new points without (packed) upper lists: default entries only
             d_upper_base.reserve(n, stream, true); d_upper_cnt.reserve(n, stream, true);
-            std::vector<uint32_t> nb(n - upper_slots, NONE32);
-            VDB_HIP(hipMemcpyAsync(d_upper_base.p + upper_slots, nb.data(), nb.size() * 4, hipMemcpyHostToDevice, stream));
+            static_assert(NONE32 == 0xFFFFFFFFu, "the byte fill below writes NONE32");
+            VDB_HIP(hipMemsetAsync(d_upper_base.p + upper_slots, 0xFF, (n - upper_slots) * 4, stream));
             VDB_HIP(hipMemsetAsync(d_upper_cnt.p + upper_slots, 0, n - upper_slots, stream));
-            VDB_HIP(hipStreamSynchronize(stream));
             upper_slots = n;
         }
         for (uint32_t s : dirty0) dirty0_mark[s] = 0;
@@ -739,24 +735,29 @@ vdb_index::BuildResult vdb_index::build_search(const std::vector<uint32_t>& slot
     std::lock_guard<std::mutex> lk(mu);
     use_device();
     sync_device(lazy_upper);
-    s_slots.reserve(nq, stream, false); s_lvl.reserve(nq, stream, false); s_off.reserve(nq + 1, stream, false);
-    s_nb.reserve(rows * m, stream, false); s_nbc.reserve(rows, stream, false);
+    // one upload (slots, levels, offsets) and one download (counts, neighbours); a single insert stages both in
+    // page-locked memory so that neither copy blocks on its own
+    const size_t in_words = 3 * nq + 1, out_words = rows * (m + 1);
+    s_bin.reserve(in_words, stream, false); s_bout.reserve(out_words, stream, false);
     s_n.reserve(nq, stream, false); s_stats.reserve(nq, stream, false);
-    VDB_HIP(hipMemcpyAsync(s_slots.p, slots.data(), nq * 4, hipMemcpyHostToDevice, stream));
-    VDB_HIP(hipMemcpyAsync(s_lvl.p, lv.data(), nq * 4, hipMemcpyHostToDevice, stream));
-    VDB_HIP(hipMemcpyAsync(s_off.p, br.off.data(), (nq + 1) * 4, hipMemcpyHostToDevice, stream));
-    VDB_HIP(hipMemsetAsync(s_nbc.p, 0, rows * 4, stream));
+    std::vector<uint32_t> pageable;
+    uint32_t* h;
+    if ((in_words + out_words) * 4 <= (size_t(256) << 10)) h = static_cast<uint32_t*>(pinned((in_words + out_words) * 4));
+    else { pageable.resize(in_words + out_words); h = pageable.data(); }
+    std::memcpy(h, slots.data(), nq * 4); std::memcpy(h + nq, lv.data(), nq * 4); std::memcpy(h + 2 * nq, br.off.data(), (nq + 1) * 4);
+    VDB_HIP(hipMemcpyAsync(s_bin.p, h, in_words * 4, hipMemcpyHostToDevice, stream));
+    VDB_HIP(hipMemsetAsync(s_bout.p, 0, rows * 4, stream));
     SearchArgs a{};
-    a.g = view(); a.mode = MODE_BUILD; a.arith = opts.arith; a.query_slots = s_slots.p; a.nq = (uint32_t)nq;
+    a.g = view(); a.mode = MODE_BUILD; a.arith = opts.arith; a.query_slots = s_bin.p; a.nq = (uint32_t)nq;
     a.entry = entry_slot; a.max_level = (uint32_t)current_max_level;
     auto fl = first_live_slot(); a.fallback_live = fl ? *fl : NONE32;
     a.ef = (uint32_t)ef; a.top_k = 0; a.out = nullptr; a.out_n = s_n.p; a.stats = s_stats.p;
     a.beam_width = 1;
-    a.q_levels = s_lvl.p; a.nb_off = s_off.p; a.m = (uint32_t)m; a.nb_out = s_nb.p; a.nb_cnt = s_nbc.p;
+    a.q_levels = s_bin.p + nq; a.nb_off = s_bin.p + 2 * nq; a.m = (uint32_t)m; a.nb_cnt = s_bout.p; a.nb_out = s_bout.p + rows;
     run_search(a, nq, stream, true, nullptr);
-    VDB_HIP(hipMemcpyAsync(br.nb.data(), s_nb.p, rows * m * 4, hipMemcpyDeviceToHost, stream));
-    VDB_HIP(hipMemcpyAsync(br.cnt.data(), s_nbc.p, rows * 4, hipMemcpyDeviceToHost, stream));
+    VDB_HIP(hipMemcpyAsync(h + in_words, s_bout.p, out_words * 4, hipMemcpyDeviceToHost, stream));
     VDB_HIP(hipStreamSynchronize(stream));
+    std::memcpy(br.cnt.data(), h + in_words, rows * 4); std::memcpy(br.nb.data(), h + in_words + rows, rows * m * 4);
     return br;
 }
 

@@ -73,7 +73,7 @@ struct vdb_index {
     uint32_t clean_epoch = 0; bool upper_dirty = true, need_full = true;
     size_t ovf_live = 0;                                      // entries of `ovf` that a block still points at
     size_t ovf_used = 0, upper_words = 0, upper_slots = 0, upper_lists_packed = 0; uint64_t entry_at_pack = ~0ull;
-    vdb::DevBuf<uint32_t> s_patch_idx, s_patch_blk, s_delta;
+    vdb::DevBuf<uint32_t> s_delta;
     // appends to layer-0 lists whose device block is otherwise current: (slot, position in the packed list, neighbour)
     std::vector<uint32_t> delta_slot, delta_pos, delta_val;
     void verify_layer0();                                    // VDB_VERIFY_DEVICE=1: device blocks against a fresh pack of the host lists
@@ -83,7 +83,7 @@ struct vdb_index {
     mutable void* h_pin = nullptr; mutable size_t h_pin_bytes = 0;     // pinned staging of small search batches (one query per call is the reference's shape)
     void* pinned(size_t bytes) const;
     mutable vdb::DevBuf<float> s_q, s_raw, s_sub_vecs; mutable vdb::DevBuf<uint64_t> s_sub_ids; mutable vdb::DevBuf<vdb_scored_point> s_out, s_knn, s_cand;
-    mutable vdb::DevBuf<uint32_t> s_knn_words, s_n, s_slots, s_qslots, s_lvl, s_off, s_nb, s_nbc, s_hash, s_spill; mutable vdb::DevBuf<vdb_query_stats> s_stats;
+    mutable vdb::DevBuf<uint32_t> s_knn_words, s_n, s_slots, s_qslots, s_lvl, s_off, s_nb, s_nbc, s_bin, s_bout, s_hash, s_spill; mutable vdb::DevBuf<vdb_query_stats> s_stats;
     mutable std::map<hipStream_t, vdb::DevBuf<vdb_query_stats>> s_stats_by_stream;
 
     vdb_index(vdb_metric metric, size_t m, size_t ef, size_t cap, size_t dim, const vdb_options& o);
