@@ -1,4 +1,6 @@
-"""Single-point insert rate (Segment::insert one by one, the reference's usage) at a given index size."""
+"""Single-point insert rate (HNSWIndex::insert one by one, the reference's usage) at a given index size.
+Second argument: `clustered` (the benchmark's generator, default) or `uniform` (uniform(0,1) coordinates: hub lists
+with thousands of entries, the hard case for a walk)."""
 import sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -6,8 +8,13 @@ import vectordb_amd
 vdb = vectordb_amd.api()
 n0 = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
 d = 128
-rng = np.random.default_rng(1)
-x = rng.uniform(0, 1, size=(n0 + 2000, d)).astype(np.float32)
+kind = sys.argv[2] if len(sys.argv) > 2 else "clustered"
+if kind == "uniform":
+    x = np.random.default_rng(1).uniform(0, 1, size=(n0 + 2000, d)).astype(np.float32)
+else:
+    from bench import clustered
+    x = clustered(n0 + 2000, d, 0xC3, np.random.default_rng(0xC2).uniform(0, 128, size=(4096, d)).astype(np.float32))
+    x = x[np.random.default_rng(2).permutation(len(x))]
 h = vdb.HNSWIndex(vdb.DistanceMetric.Euclidean, 16, 64, 16, d)
 h.insert_batch(np.arange(n0, dtype=np.uint64), x[:n0])
 t0 = time.time()
@@ -17,4 +24,4 @@ dt = time.time() - t0
 q = x[n0:n0 + 100]
 out, cnt = h.search_batch(q, 1)
 assert (out["id"][:, 0] == np.arange(n0, n0 + 100)).mean() > 0.95, "freshly inserted points must be found"
-print(f"{2000/dt:.0f} single inserts/s at {n0} points ({dt/2000*1e3:.2f} ms each)")
+print(f"{2000/dt:.0f} single inserts/s at {n0} {kind} points ({dt/2000*1e3:.2f} ms each)")

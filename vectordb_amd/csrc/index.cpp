@@ -752,7 +752,9 @@ vdb_index::BuildResult vdb_index::build_search(const std::vector<uint32_t>& slot
     a.entry = entry_slot; a.max_level = (uint32_t)current_max_level;
     auto fl = first_live_slot(); a.fallback_live = fl ? *fl : NONE32;
     a.ef = (uint32_t)ef; a.top_k = 0; a.out = nullptr; a.out_n = s_n.p; a.stats = s_stats.p;
-    a.beam_width = 1;
+    // a handful of points cannot fill the GPU: their walks take several parents per step, which shortens the
+    // chain of dependent steps (the explored set only grows); STRICT keeps the reference's one parent per step
+    a.beam_width = (opts.arith == VDB_ARITH_FAST && nq <= 256) ? beam_width() : 1;
     a.q_levels = s_bin.p + nq; a.nb_off = s_bin.p + 2 * nq; a.m = (uint32_t)m; a.nb_cnt = s_bout.p; a.nb_out = s_bout.p + rows;
     run_search(a, nq, stream, true, nullptr);
     VDB_HIP(hipMemcpyAsync(h + in_words, s_bout.p, out_words * 4, hipMemcpyDeviceToHost, stream));
@@ -797,7 +799,9 @@ void vdb_index::insert(uint64_t id, const float* v, size_t len) {
     if (!entry_point) { entry_point = id; current_max_level = levels[s]; return; }  // hnsw.rs:150-155
     uint32_t ep = slot_of.at(*entry_point);
     if (deleted[ep]) { auto f = first_live_slot(); if (f) ep = *f; }                 // hnsw.rs:158-164
-    BuildResult br = build_search({s}, ep);
+    // FAST: the walk may use upper layers packed a few inserts ago (re-packing them costs O(n); the next search by a
+    // caller, or 1/16 more upper lists, brings them up to date); STRICT always walks the current graph
+    BuildResult br = build_search({s}, ep, opts.arith == VDB_ARITH_FAST);
     link_point(s, br, 0);
 }
 

@@ -921,9 +921,20 @@ void launch_search_shape(const SearchArgs& a, size_t lds, hipStream_t st) {
     const uint32_t chunks = a.g.stride / 4;
     constexpr int P8 = NC > 0 ? 2 : 4;             // row groups in flight per lane for short rows
     constexpr int P64 = NC > 0 ? 4 : 8;            // rows in flight per wave for long rows (x 2 chunks: half of it)
-    if (chunks <= 32) hipLaunchKernelGGL((search_kernel<MODE, 8, 4, P8, false, METRIC, NC>), dim3(a.nq), dim3(64), lds, st, a);
-    else if (chunks <= 256) hipLaunchKernelGGL((search_kernel<MODE, 64, 4, P64, false, METRIC, NC>), dim3(a.nq), dim3(64), lds, st, a);
-    else if (chunks <= 512) hipLaunchKernelGGL((search_kernel<MODE, 64, 8, P64 / 2, false, METRIC, NC>), dim3(a.nq), dim3(64), lds, st, a);
+    // A launch of at most one wavefront per SIMD has no other wavefront to hide a row fetch behind: its walks keep
+    // four times as many rows in flight per wavefront (more registers, the same sums in the same order).
+    constexpr bool HAS_FEW = NC > 0 && (MODE == MODE_SEARCH || MODE == MODE_BUILD);
+    const bool few = HAS_FEW && a.nq <= 1024;
+    if (chunks <= 32) {
+        if (few) hipLaunchKernelGGL((search_kernel<MODE, 8, 4, HAS_FEW ? 8 : P8, false, METRIC, NC>), dim3(a.nq), dim3(64), lds, st, a);
+        else hipLaunchKernelGGL((search_kernel<MODE, 8, 4, P8, false, METRIC, NC>), dim3(a.nq), dim3(64), lds, st, a);
+    } else if (chunks <= 256) {
+        if (few) hipLaunchKernelGGL((search_kernel<MODE, 64, 4, HAS_FEW ? 16 : P64, false, METRIC, NC>), dim3(a.nq), dim3(64), lds, st, a);
+        else hipLaunchKernelGGL((search_kernel<MODE, 64, 4, P64, false, METRIC, NC>), dim3(a.nq), dim3(64), lds, st, a);
+    } else if (chunks <= 512) {
+        if (few) hipLaunchKernelGGL((search_kernel<MODE, 64, 8, HAS_FEW ? 8 : P64 / 2, false, METRIC, NC>), dim3(a.nq), dim3(64), lds, st, a);
+        else hipLaunchKernelGGL((search_kernel<MODE, 64, 8, P64 / 2, false, METRIC, NC>), dim3(a.nq), dim3(64), lds, st, a);
+    }
     else throw Failure(err_arg("dimension above 2048 is not supported"));
 }
 template <int MODE, int METRIC>
