@@ -21,7 +21,13 @@ t0 = time.time()
 for i in range(n0, n0 + 2000):
     h.insert(i, x[i])
 dt = time.time() - t0
+t0 = time.time()
+for i in range(n0 + 1000, n0 + 2000):          # mixed traffic: every insert is followed by a search
+    h.search(x[i], 10)
+    h.insert(i + 1000000000, x[i] * np.float32(0.999))
+dm = time.time() - t0
 q = x[n0:n0 + 100]
 out, cnt = h.search_batch(q, 1)
 assert (out["id"][:, 0] == np.arange(n0, n0 + 100)).mean() > 0.95, "freshly inserted points must be found"
+print(f"alternating insert + search: {dm/1000*1e3:.2f} ms per pair")
 print(f"{2000/dt:.0f} single inserts/s at {n0} {kind} points ({dt/2000*1e3:.2f} ms each)")

@@ -306,7 +306,7 @@ void vdb_index::pack_upper() {
     upper_slots = n;
 }
 
-void vdb_index::sync_device(bool for_build) {
+void vdb_index::sync_device(uint32_t upper_slack) {
     use_device();
     const size_t n = ids.size();
     if (graph_dirty) {
@@ -315,13 +315,14 @@ void vdb_index::sync_device(bool for_build) {
                           ovf_used > 8 * ovf_live + (size_t(1) << 22);          // mostly dead overflow runs: pack anew
         if (full) pack_layer0_full(); else patch_layer0();
         bool upper_now = full || upper_dirty;
-        if (upper_now && !full && for_build && d_upper_base.cap != 0) {
-            // between rounds of the batched builder: keep the packed upper layers until they lack 1/16 of their
-            // lists or the entry point moved (every search of a caller still sees them complete)
+        if (upper_now && !full && upper_slack != 0 && d_upper_base.cap != 0) {
+            // the caller accepts packed upper layers that lack up to 1/upper_slack of their lists (they only route a
+            // walk towards its layer-0 start; layer 0 is always current): rounds of the batched builder take 1/16,
+            // FAST searches and single inserts less; a moved entry point always re-packs
             size_t lists = 0;
             for (size_t l = 1; l < layers.size(); ++l) lists += layers[l].lists.size();
             const uint64_t ep = entry_point ? *entry_point : ~0ull;
-            if (ep == entry_at_pack && (lists - upper_lists_packed) * 16 <= upper_lists_packed) upper_now = false;
+            if (ep == entry_at_pack && (lists - upper_lists_packed) * upper_slack <= upper_lists_packed) upper_now = false;
         }
         if (upper_now) {
             pack_upper();
@@ -450,7 +451,7 @@ void vdb_index::search_batch(const float* q, size_t nq, size_t top_k, size_t ef_
         return;
     }
     if (top_k == 0) { std::memset(out_n, 0, nq * sizeof(uint32_t)); return; }
-    sync_device();
+    sync_device(opts.arith == VDB_ARITH_FAST && fa.mode == MODE_SEARCH ? UPPER_SLACK_SEARCH : 0);
     s_q.reserve(nq * dim, stream, false); s_out.reserve(nq * top_k, stream, false);
     s_n.reserve(nq, stream, false); s_stats.reserve(nq, stream, false);
     // small batches go through pinned host memory: copies from and to pageable memory cost more than the search of one query
@@ -511,7 +512,7 @@ void vdb_index::search_batch_dev(const float* d_q, size_t nq, size_t top_k, size
     const size_t ef_ = ef_search ? ef_search : ef;
     if (ef_ > MAX_EF) throw Failure(err_arg("ef_search must be <= 1024"));
     if (!entry_point) { VDB_HIP(hipMemsetAsync(d_out_n, 0, nq * sizeof(uint32_t), s)); return; }
-    sync_device();
+    sync_device(opts.arith == VDB_ARITH_FAST ? UPPER_SLACK_SEARCH : 0);
     SearchArgs a{};
     a.g = view(); a.mode = MODE_SEARCH; a.arith = opts.arith; a.queries = d_q; a.nq = (uint32_t)nq;
     a.entry = slot_of.at(*entry_point); a.max_level = (uint32_t)current_max_level;
@@ -734,7 +735,7 @@ vdb_index::BuildResult vdb_index::build_search(const std::vector<uint32_t>& slot
     br.nb.assign(rows * m, 0); br.cnt.assign(rows, 0);
     std::lock_guard<std::mutex> lk(mu);
     use_device();
-    sync_device(lazy_upper);
+    sync_device(lazy_upper ? UPPER_SLACK_BUILD : 0);
     // one upload (slots, levels, offsets) and one download (counts, neighbours); a single insert stages both in
     // page-locked memory so that neither copy blocks on its own
     const size_t in_words = 3 * nq + 1, out_words = rows * (m + 1);
@@ -799,8 +800,8 @@ void vdb_index::insert(uint64_t id, const float* v, size_t len) {
     if (!entry_point) { entry_point = id; current_max_level = levels[s]; return; }  // hnsw.rs:150-155
     uint32_t ep = slot_of.at(*entry_point);
     if (deleted[ep]) { auto f = first_live_slot(); if (f) ep = *f; }                 // hnsw.rs:158-164
-    // FAST: the walk may use upper layers packed a few inserts ago (re-packing them costs O(n); the next search by a
-    // caller, or 1/16 more upper lists, brings them up to date); STRICT always walks the current graph
+    // FAST: the walk may use upper layers packed some inserts ago (re-packing them costs O(n) and waits until they
+    // lack a fraction of their lists, see sync_device); STRICT always walks the current graph
     BuildResult br = build_search({s}, ep, opts.arith == VDB_ARITH_FAST);
     link_point(s, br, 0);
 }

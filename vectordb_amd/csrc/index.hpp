@@ -107,7 +107,9 @@ struct vdb_index {
     // device
     // upload rows / packed graph / tombstones if stale.  for_build: a round of the batched builder may search upper
     // layers that lack the newest few percent of their nodes (they are re-packed as a whole, which costs O(n))
-    void sync_device(bool for_build = false);
+    // upper_slack: 0 = the device copy must be complete; k = packed upper layers may lack up to 1/k of their lists
+    static constexpr uint32_t UPPER_SLACK_BUILD = 16, UPPER_SLACK_SEARCH = 256;
+    void sync_device(uint32_t upper_slack = 0);
     void pack_layer0_full(); void patch_layer0(); void pack_upper();
     void clean_list(const std::vector<uint32_t>& src, uint32_t self, std::vector<uint32_t>& out);
     static void fill_block(uint32_t* blk, const std::vector<uint32_t>& lst, std::vector<uint32_t>& ovf, size_t ovf_base);
