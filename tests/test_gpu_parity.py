@@ -155,6 +155,34 @@ def test_single_insert_builds_the_same_graph(ora, vdb, metric):
         assert np.array_equal(ow, ow2) and np.array_equal(of, of2) and np.array_equal(nb, nb2)
 
 
+def test_single_inserts_patch_the_upper_layers(vdb, monkeypatch):
+    """Single inserts bring the packed upper layers on the GPU up to date list by list (new owners, relocated lists,
+    fused blocks) instead of re-packing them; VDB_VERIFY_DEVICE makes every sync compare the device copy with the host
+    lists.  A point is found by its own vector as soon as its insert returns, and the final graph answers like the
+    same graph imported (and therefore packed from scratch) into a fresh index."""
+    monkeypatch.setenv("VDB_VERIFY_DEVICE", "1")
+    n0, extra, d, k = 4000, 800, 32, 10
+    x = data(n0 + extra, d, 77)            # uniform rows: one connected graph, so a walk always reaches its own point
+    h = vdb.HNSWIndex(vdb.DistanceMetric.Euclidean, 8, 48, 16, d, seed=9)
+    h.insert_batch(np.arange(n0, dtype=np.uint64), x[:n0])
+    for i in range(n0, n0 + extra):
+        h.insert(i, x[i])
+        if i % 3 == 0:
+            out = h.search(x[i], 1)
+            assert out[0].id == i and out[0].raw_score <= 1e-3, "a point is findable as soon as its insert returns"
+    g = h.export_graph()
+    assert len(g["ids"]) == n0 + extra and int(g["levels"][n0:].max()) >= 1, "some new points own upper lists"
+    owners0 = set(g["layers"][0][0].tolist())
+    assert all(s in owners0 for s in range(n0, n0 + extra))
+    q = data(300, d, 78)
+    got, gotn = h.search_batch(q, k, ef_search=64)
+    fresh = vdb.HNSWIndex(vdb.DistanceMetric.Euclidean, 8, 48, 16, d, seed=9); fresh.import_graph(g)
+    ref, refn = fresh.search_batch(q, k, ef_search=64)
+    truth, _ = fresh.exact_knn_batch(q, k)
+    rec = lambda o: np.mean([len(set(o["id"][i].tolist()) & set(truth["id"][i].tolist())) / k for i in range(len(q))])
+    assert np.array_equal(got["id"], ref["id"]) and np.array_equal(gotn, refn), (rec(got), rec(ref))
+
+
 @pytest.mark.parametrize("metric", [0, 1, 2])
 def test_exact_knn_bit_exact(ora, vdb, metric):
     n, d, nq, k = 5000, 48, 64, 10

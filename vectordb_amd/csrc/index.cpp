@@ -63,7 +63,10 @@ std::vector<uint32_t>& vdb_index::list_or_default(size_t level, uint32_t slot) {
     if (level == 0) {                       // the device copy of layer 0 is patched list by list
         if (dirty0_mark.size() <= slot) dirty0_mark.resize(std::max<size_t>(slot + 1, ids.size()), 0);
         if (!dirty0_mark[slot]) { dirty0_mark[slot] = 1; dirty0.push_back(slot); }
-    } else upper_dirty = true;
+    } else {
+        upper_dirty = true;
+        if (dirty_upper.size() < (size_t(1) << 22)) dirty_upper.push_back((uint64_t)level << 32 | slot); else dirty_upper_lost = true;
+    }
     return L.lists[L.idx[slot]];
 }
 
@@ -304,6 +307,139 @@ void vdb_index::pack_upper() {
     }
     VDB_HIP(hipStreamSynchronize(stream));
     upper_slots = n;
+    pool_used = pool_live = pool.size();
+    h_upper_base.swap(upper_base); h_upper_cnt.swap(upper_cnt); h_udesc.swap(udesc);
+    dirty_upper.clear(); dirty_upper_lost = false;
+}
+
+// Brings the packed upper layers up to date list by list: a changed list is written anew at the end of `pool` (its old
+// run becomes dead space), its descriptor and its fused block are overwritten, a new owner gets descriptors and
+// blocks at the end.  Returns false when a whole re-pack is the better or the only way (many lists changed, mostly
+// dead pool, an owner that gained a layer, counts beyond the packed references).
+bool vdb_index::patch_upper() {
+    const size_t n = ids.size();
+    if (!have_ublk || dirty_upper_lost || d_upper_base.cap == 0 || h_upper_base.size() < upper_slots || upper_slots > n) return false;
+    std::sort(dirty_upper.begin(), dirty_upper.end());
+    dirty_upper.erase(std::unique(dirty_upper.begin(), dirty_upper.end()), dirty_upper.end());
+    if (dirty_upper.size() * 8 > h_udesc.size() + 64 || pool_used > 2 * pool_live + (size_t(1) << 20)) return false;
+    // new owners first: every block written below may refer to them
+    std::vector<uint32_t> fresh;
+    // the mirror is edited in place: every `return false` below is followed by a whole re-pack, which rebuilds it
+    std::vector<uint32_t>& nbase = h_upper_base; std::vector<uint8_t>& ncnt = h_upper_cnt; std::vector<uint64_t>& ndesc = h_udesc;
+    nbase.resize(n, NONE32); ncnt.resize(n, 0);
+    std::vector<uint64_t> todo;
+    for (uint64_t key : dirty_upper) {
+        const uint32_t l = (uint32_t)(key >> 32), s = (uint32_t)key;
+        if (s >= n || !list(l, s)) return false;
+        if (ncnt[s] == 0) {
+            uint32_t cnt = 0;
+            for (size_t k = 1; k < layers.size(); ++k) if (list(k, s)) cnt = (uint32_t)k;
+            if (cnt > 63) return false;
+            nbase[s] = (uint32_t)ndesc.size(); ncnt[s] = (uint8_t)cnt;
+            for (uint32_t k = 1; k <= cnt; ++k) { ndesc.push_back(make_desc(0, 0)); todo.push_back((uint64_t)k << 32 | s); }
+            fresh.push_back(s);
+        } else if (l > ncnt[s]) return false;
+        else todo.push_back(key);
+    }
+    std::sort(todo.begin(), todo.end());
+    todo.erase(std::unique(todo.begin(), todo.end()), todo.end());
+    if (ndesc.size() >= (size_t(1) << UREF_BITS)) return false;
+    std::vector<uint32_t> tail, didx, tmp;
+    size_t live = pool_live;
+    for (uint64_t key : todo) {
+        const uint32_t l = (uint32_t)(key >> 32), s = (uint32_t)key;
+        const uint32_t di = nbase[s] + l - 1;
+        const std::vector<uint32_t>* lst = list(l, s);
+        if (lst) clean_list(*lst, s, tmp); else tmp.clear();
+        live += tmp.size(); live -= (size_t)(ndesc[di] >> 40);
+        ndesc[di] = make_desc(pool_used + tail.size(), (uint32_t)tmp.size());
+        tail.insert(tail.end(), tmp.begin(), tmp.end());
+        didx.push_back(di);
+    }
+    if (pool_used + tail.size() >= (size_t(1) << 32)) return false;
+    // staged upload: descriptor indices, blocks, reference blocks, descriptor words (index, value), owner words
+    const size_t nd = didx.size(), nf = fresh.size();
+    std::vector<uint32_t> st(nd + 2 * nd * ADJ_BLOCK + 4 * nd + 2 * nf, 0);
+    uint32_t* blk0 = st.data() + nd; uint32_t* ref0 = blk0 + nd * ADJ_BLOCK;
+    uint32_t* widx = ref0 + nd * ADJ_BLOCK; uint32_t* wval = widx + 2 * nd; uint32_t* oidx = wval + 2 * nd; uint32_t* oval = oidx + nf;
+    for (size_t i = 0; i < nd; ++i) {
+        const uint32_t di = didx[i];
+        const uint64_t off = ndesc[di] & 0xFFFFFFFFFFull; const uint32_t deg = (uint32_t)(ndesc[di] >> 40);
+        const uint32_t* run = tail.data() + (off - pool_used);
+        uint32_t* blk = blk0 + i * ADJ_BLOCK; uint32_t* ref = ref0 + i * ADJ_BLOCK;
+        st[i] = di;
+        blk[0] = deg; blk[63] = (uint32_t)(off + ADJ_INLINE);
+        for (uint32_t j = 0; j < std::min<uint32_t>(deg, ADJ_INLINE); ++j) { blk[1 + j] = run[j]; ref[1 + j] = make_uref(nbase[run[j]], ncnt[run[j]]); }
+        widx[2 * i] = 2 * di; widx[2 * i + 1] = 2 * di + 1;
+        wval[2 * i] = (uint32_t)ndesc[di]; wval[2 * i + 1] = (uint32_t)(ndesc[di] >> 32);
+    }
+    for (size_t i = 0; i < nf; ++i) { oidx[i] = fresh[i]; oval[i] = nbase[fresh[i]]; }
+    d_upper_base.reserve(n, stream, true); d_upper_cnt.reserve(n, stream, true);
+    d_udesc.reserve(ndesc.size(), stream, true); d_ublk.reserve(ndesc.size() * ADJ_BLOCK, stream, true); d_ublk_ref.reserve(ndesc.size() * ADJ_BLOCK, stream, true);
+    d_pool.reserve(std::max<size_t>(pool_used + tail.size(), 1), stream, true);
+    if (upper_slots != n) {                       // slots added since the last sync own nothing until told otherwise
+        VDB_HIP(hipMemsetAsync(d_upper_base.p + upper_slots, 0xFF, (n - upper_slots) * 4, stream));
+        VDB_HIP(hipMemsetAsync(d_upper_cnt.p + upper_slots, 0, n - upper_slots, stream));
+    }
+    if (!tail.empty()) VDB_HIP(hipMemcpyAsync(d_pool.p + pool_used, tail.data(), tail.size() * 4, hipMemcpyHostToDevice, stream));
+    if (!st.empty()) {
+        uint32_t* h = st.data();
+        if (st.size() * 4 <= (size_t(256) << 10)) { h = static_cast<uint32_t*>(pinned(st.size() * 4)); std::memcpy(h, st.data(), st.size() * 4); }
+        s_delta.reserve(st.size(), stream, false);
+        VDB_HIP(hipMemcpyAsync(s_delta.p, h, st.size() * 4, hipMemcpyHostToDevice, stream));
+        const uint32_t* d = s_delta.p;
+        launch_patch_blocks(d_ublk.p, d, d + nd, (uint32_t)nd, stream);
+        launch_patch_blocks(d_ublk_ref.p, d, d + nd + nd * ADJ_BLOCK, (uint32_t)nd, stream);
+        launch_patch_words(reinterpret_cast<uint32_t*>(d_udesc.p), d + nd + 2 * nd * ADJ_BLOCK, d + nd + 2 * nd * ADJ_BLOCK + 2 * nd, (uint32_t)(2 * nd), stream);
+        launch_patch_words(d_upper_base.p, d + nd + 2 * nd * ADJ_BLOCK + 4 * nd, d + nd + 2 * nd * ADJ_BLOCK + 4 * nd + nf, (uint32_t)nf, stream);
+    }
+    for (uint32_t s : fresh) VDB_HIP(hipMemsetAsync(d_upper_cnt.p + s, ncnt[s], 1, stream));
+    VDB_HIP(hipStreamSynchronize(stream));
+    pool_used += tail.size(); pool_live = live;
+    upper_slots = n;
+    upper_edges = pool_live; upper_words = h_udesc.size() * 2 + pool_used + h_udesc.size() * ADJ_BLOCK * 2;
+    dirty_upper.clear();
+    return true;
+}
+
+// Diagnostic (VDB_VERIFY_DEVICE=1): the packed upper layers on the device must describe the host lists, however
+// many patches and re-packs produced them.
+void vdb_index::verify_upper() {
+    const size_t n = ids.size();
+    if (n == 0 || !have_ublk || upper_slots != n) return;
+    std::vector<uint32_t> base(n), pool(std::max<size_t>(pool_used, 1)), blk(std::max<size_t>(h_udesc.size(), 1) * ADJ_BLOCK), ref(blk.size()), tmp;
+    std::vector<uint8_t> cnt(n); std::vector<uint64_t> desc(std::max<size_t>(h_udesc.size(), 1));
+    VDB_HIP(hipMemcpyAsync(base.data(), d_upper_base.p, n * 4, hipMemcpyDeviceToHost, stream));
+    VDB_HIP(hipMemcpyAsync(cnt.data(), d_upper_cnt.p, n, hipMemcpyDeviceToHost, stream));
+    if (!h_udesc.empty()) {
+        VDB_HIP(hipMemcpyAsync(desc.data(), d_udesc.p, h_udesc.size() * 8, hipMemcpyDeviceToHost, stream));
+        VDB_HIP(hipMemcpyAsync(blk.data(), d_ublk.p, h_udesc.size() * ADJ_BLOCK * 4, hipMemcpyDeviceToHost, stream));
+        VDB_HIP(hipMemcpyAsync(ref.data(), d_ublk_ref.p, h_udesc.size() * ADJ_BLOCK * 4, hipMemcpyDeviceToHost, stream));
+    }
+    if (pool_used) VDB_HIP(hipMemcpyAsync(pool.data(), d_pool.p, pool_used * 4, hipMemcpyDeviceToHost, stream));
+    VDB_HIP(hipStreamSynchronize(stream));
+    auto fail = [&](uint32_t s, size_t l, const char* what) {
+        throw Failure(err_device("device copy of the upper layers differs from the host lists (slot " + std::to_string(s) + ", layer " + std::to_string(l) + ": " + what + ")"));
+    };
+    for (uint32_t s = 0; s < n; ++s) {
+        uint32_t want = 0;
+        for (size_t l = 1; l < layers.size(); ++l) if (list(l, s)) want = (uint32_t)l;
+        if (cnt[s] != want) fail(s, want, "layer count");
+        if (!want) continue;
+        if ((size_t)base[s] + want > h_udesc.size()) fail(s, want, "descriptor range");
+        for (uint32_t l = 1; l <= want; ++l) {
+            const size_t di = (size_t)base[s] + l - 1;
+            const std::vector<uint32_t>* lst = list(l, s);
+            if (lst) clean_list(*lst, s, tmp); else tmp.clear();
+            const uint64_t off = desc[di] & 0xFFFFFFFFFFull; const uint32_t deg = (uint32_t)(desc[di] >> 40);
+            if (deg != tmp.size() || off + deg > pool_used) fail(s, l, "degree");
+            if (!std::equal(tmp.begin(), tmp.end(), pool.begin() + off)) fail(s, l, "pool run");
+            const uint32_t* b = &blk[di * ADJ_BLOCK]; const uint32_t* r = &ref[di * ADJ_BLOCK];
+            if (b[0] != deg || b[63] != (uint32_t)(off + ADJ_INLINE)) fail(s, l, "block header");
+            for (uint32_t j = 0; j < std::min<uint32_t>(deg, ADJ_INLINE); ++j)
+                if (b[1 + j] != tmp[j] || r[1 + j] != make_uref(base[tmp[j]], cnt[tmp[j]])) fail(s, l, "block entry");
+        }
+    }
 }
 
 void vdb_index::sync_device(uint32_t upper_slack) {
@@ -316,20 +452,20 @@ void vdb_index::sync_device(uint32_t upper_slack) {
         if (full) pack_layer0_full(); else patch_layer0();
         bool upper_now = full || upper_dirty;
         if (upper_now && !full && upper_slack != 0 && d_upper_base.cap != 0) {
-            // the caller accepts packed upper layers that lack up to 1/upper_slack of their lists (they only route a
-            // walk towards its layer-0 start; layer 0 is always current): rounds of the batched builder take 1/16,
-            // FAST searches and single inserts less; a moved entry point always re-packs
+            // between rounds of the batched builder: the packed upper layers may lack up to 1/upper_slack of their lists
+            // (they only route a walk towards its layer-0 start; layer 0 is always current) unless the entry point
+            // moved; every search of a caller and every single insert sees them complete
             size_t lists = 0;
             for (size_t l = 1; l < layers.size(); ++l) lists += layers[l].lists.size();
             const uint64_t ep = entry_point ? *entry_point : ~0ull;
             if (ep == entry_at_pack && (lists - upper_lists_packed) * upper_slack <= upper_lists_packed) upper_now = false;
         }
-        if (upper_now) {
-            pack_upper();
+        if (upper_now && !full && patch_upper()) upper_now = false, upper_dirty = false;
+        else if (upper_now) { pack_upper(); upper_dirty = false; }
+        if (!upper_dirty) {
             upper_lists_packed = 0;
             for (size_t l = 1; l < layers.size(); ++l) upper_lists_packed += layers[l].lists.size();
             entry_at_pack = entry_point ? *entry_point : ~0ull;
-            upper_dirty = false;
         }
         if (!upper_now && upper_slots != n) {    // new points without (packed) upper lists: default entries only
             d_upper_base.reserve(n, stream, true); d_upper_cnt.reserve(n, stream, true);
@@ -337,10 +473,11 @@ void vdb_index::sync_device(uint32_t upper_slack) {
             VDB_HIP(hipMemsetAsync(d_upper_base.p + upper_slots, 0xFF, (n - upper_slots) * 4, stream));
             VDB_HIP(hipMemsetAsync(d_upper_cnt.p + upper_slots, 0, n - upper_slots, stream));
             upper_slots = n;
+            h_upper_base.resize(n, NONE32); h_upper_cnt.resize(n, 0);
         }
         for (uint32_t s : dirty0) dirty0_mark[s] = 0;
         dirty0.clear(); need_full = false;
-        if (getenv("VDB_VERIFY_DEVICE")) verify_layer0();
+        if (getenv("VDB_VERIFY_DEVICE")) { verify_layer0(); if (!upper_dirty) verify_upper(); }
         device_bytes = n * (size_t)stride * 4 + n * 8 + n * ADJ_BLOCK * 4 + ovf_used * 4 + n * 5 + upper_words * 4;
         graph_dirty = upper_dirty;               // a postponed upper re-pack keeps the copy stale for other callers
     }
@@ -451,7 +588,7 @@ void vdb_index::search_batch(const float* q, size_t nq, size_t top_k, size_t ef_
         return;
     }
     if (top_k == 0) { std::memset(out_n, 0, nq * sizeof(uint32_t)); return; }
-    sync_device(opts.arith == VDB_ARITH_FAST && fa.mode == MODE_SEARCH ? UPPER_SLACK_SEARCH : 0);
+    sync_device();
     s_q.reserve(nq * dim, stream, false); s_out.reserve(nq * top_k, stream, false);
     s_n.reserve(nq, stream, false); s_stats.reserve(nq, stream, false);
     // small batches go through pinned host memory: copies from and to pageable memory cost more than the search of one query
@@ -512,7 +649,7 @@ void vdb_index::search_batch_dev(const float* d_q, size_t nq, size_t top_k, size
     const size_t ef_ = ef_search ? ef_search : ef;
     if (ef_ > MAX_EF) throw Failure(err_arg("ef_search must be <= 1024"));
     if (!entry_point) { VDB_HIP(hipMemsetAsync(d_out_n, 0, nq * sizeof(uint32_t), s)); return; }
-    sync_device(opts.arith == VDB_ARITH_FAST ? UPPER_SLACK_SEARCH : 0);
+    sync_device();
     SearchArgs a{};
     a.g = view(); a.mode = MODE_SEARCH; a.arith = opts.arith; a.queries = d_q; a.nq = (uint32_t)nq;
     a.entry = slot_of.at(*entry_point); a.max_level = (uint32_t)current_max_level;
@@ -800,9 +937,7 @@ void vdb_index::insert(uint64_t id, const float* v, size_t len) {
     if (!entry_point) { entry_point = id; current_max_level = levels[s]; return; }  // hnsw.rs:150-155
     uint32_t ep = slot_of.at(*entry_point);
     if (deleted[ep]) { auto f = first_live_slot(); if (f) ep = *f; }                 // hnsw.rs:158-164
-    // FAST: the walk may use upper layers packed some inserts ago (re-packing them costs O(n) and waits until they
-    // lack a fraction of their lists, see sync_device); STRICT always walks the current graph
-    BuildResult br = build_search({s}, ep, opts.arith == VDB_ARITH_FAST);
+    BuildResult br = build_search({s}, ep);
     link_point(s, br, 0);
 }
 

@@ -73,6 +73,11 @@ struct vdb_index {
     uint32_t clean_epoch = 0; bool upper_dirty = true, need_full = true;
     size_t ovf_live = 0;                                      // entries of `ovf` that a block still points at
     size_t ovf_used = 0, upper_words = 0, upper_slots = 0, upper_lists_packed = 0; uint64_t entry_at_pack = ~0ull;
+    // host mirror of the packed upper layers, kept so that a few changed lists can be patched instead of re-packing
+    std::vector<uint32_t> h_upper_base; std::vector<uint8_t> h_upper_cnt; std::vector<uint64_t> h_udesc;
+    std::vector<uint64_t> dirty_upper;          // (level << 32 | slot) of upper lists changed since the last sync, with repeats
+    bool dirty_upper_lost = false;              // too many to remember: re-pack
+    size_t pool_used = 0, pool_live = 0;        // words of `pool` in use on the device / referenced by a descriptor
     vdb::DevBuf<uint32_t> s_delta;
     // appends to layer-0 lists whose device block is otherwise current: (slot, position in the packed list, neighbour)
     std::vector<uint32_t> delta_slot, delta_pos, delta_val;
@@ -108,9 +113,9 @@ struct vdb_index {
     // upload rows / packed graph / tombstones if stale.  for_build: a round of the batched builder may search upper
     // layers that lack the newest few percent of their nodes (they are re-packed as a whole, which costs O(n))
     // upper_slack: 0 = the device copy must be complete; k = packed upper layers may lack up to 1/k of their lists
-    static constexpr uint32_t UPPER_SLACK_BUILD = 16, UPPER_SLACK_SEARCH = 256;
+    static constexpr uint32_t UPPER_SLACK_BUILD = 16;
     void sync_device(uint32_t upper_slack = 0);
-    void pack_layer0_full(); void patch_layer0(); void pack_upper();
+    void pack_layer0_full(); void patch_layer0(); void pack_upper(); bool patch_upper(); void verify_upper();
     void clean_list(const std::vector<uint32_t>& src, uint32_t self, std::vector<uint32_t>& out);
     static void fill_block(uint32_t* blk, const std::vector<uint32_t>& lst, std::vector<uint32_t>& ovf, size_t ovf_base);
     vdb::GraphView view() const;

@@ -391,6 +391,18 @@ void launch_patch_entries(uint32_t* adj0, const uint32_t* slot, const uint32_t* 
     VDB_HIP(hipGetLastError());
 }
 
+namespace {
+__global__ void __launch_bounds__(256) patch_words_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ val, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[idx[i]] = val[i];
+}
+}  // namespace
+void launch_patch_words(uint32_t* dst, const uint32_t* idx, const uint32_t* val, uint32_t n, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(patch_words_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dst, idx, val, n);
+    VDB_HIP(hipGetLastError());
+}
+
 void launch_patch_blocks(uint32_t* adj0, const uint32_t* idx, const uint32_t* blocks, uint32_t n, hipStream_t st) {
     if (n == 0) return;
     hipLaunchKernelGGL(patch_blocks_kernel, dim3(n), dim3(64), 0, st, adj0, idx, blocks);

@@ -99,6 +99,8 @@ void launch_exact_knn(const GraphView& g, const float* queries, uint32_t nq, uin
                       vdb_scored_point* scratch, uint32_t n_chunks, hipStream_t s);
 // adj0 block idx[i] <- blocks[i] (64 dwords each): device copy of the layer-0 lists edited on the host.
 void launch_patch_blocks(uint32_t* adj0, const uint32_t* idx, const uint32_t* blocks, uint32_t n, hipStream_t s);
+// dst[idx[i]] = val[i] for i < n (distinct idx).
+void launch_patch_words(uint32_t* dst, const uint32_t* idx, const uint32_t* val, uint32_t n, hipStream_t st);
 // out_vecs row j <- row slots[j] of the table (stride floats), out_ids[j] <- its PointId.
 void launch_gather_rows(const GraphView& g, const uint32_t* slots, uint32_t n, float* out_vecs, uint64_t* out_ids, hipStream_t s);
 // adj0 block slot[i]: neighbour word 1 + pos[i] <- val[i], degree word <- max(degree, pos[i] + 1): appends to layer-0 lists.
