@@ -214,14 +214,18 @@ void vdb_index::patch_layer0() {
     // entries go first, a list that was also edited some other way is then re-packed as a whole
     const size_t nd = delta_slot.size(), words = 3 * nd + idx.size() + blocks.size();
     if (words) {
-        std::vector<uint32_t> pageable;
-        uint32_t* h;
-        if (words * 4 <= (size_t(256) << 10)) h = static_cast<uint32_t*>(pinned(words * 4));
-        else { pageable.resize(words); h = pageable.data(); }
-        std::memcpy(h, delta_slot.data(), nd * 4); std::memcpy(h + nd, delta_pos.data(), nd * 4); std::memcpy(h + 2 * nd, delta_val.data(), nd * 4);
-        std::memcpy(h + 3 * nd, idx.data(), idx.size() * 4); std::memcpy(h + 3 * nd + idx.size(), blocks.data(), blocks.size() * 4);
         s_delta.reserve(words, stream, false);
-        VDB_HIP(hipMemcpyAsync(s_delta.p, h, words * 4, hipMemcpyHostToDevice, stream));
+        const std::pair<const uint32_t*, size_t> parts[5] = {{delta_slot.data(), nd}, {delta_pos.data(), nd}, {delta_val.data(), nd},
+                                                             {idx.data(), idx.size()}, {blocks.data(), blocks.size()}};
+        if (words * 4 <= (size_t(256) << 10)) {
+            uint32_t* h = static_cast<uint32_t*>(pinned(words * 4));
+            size_t o = 0;
+            for (auto& pr : parts) { std::memcpy(h + o, pr.first, pr.second * 4); o += pr.second; }
+            VDB_HIP(hipMemcpyAsync(s_delta.p, h, words * 4, hipMemcpyHostToDevice, stream));
+        } else {                                  // a round of the batched builder: no second host copy of its blocks
+            size_t o = 0;
+            for (auto& pr : parts) { if (pr.second) VDB_HIP(hipMemcpyAsync(s_delta.p + o, pr.first, pr.second * 4, hipMemcpyHostToDevice, stream)); o += pr.second; }
+        }
         if (nd) launch_patch_entries(d_adj0.p, s_delta.p, s_delta.p + nd, s_delta.p + 2 * nd, (uint32_t)nd, stream);
         if (!idx.empty()) launch_patch_blocks(d_adj0.p, s_delta.p + 3 * nd, s_delta.p + 3 * nd + idx.size(), (uint32_t)idx.size(), stream);
     }
@@ -319,6 +323,7 @@ void vdb_index::pack_upper() {
 bool vdb_index::patch_upper() {
     const size_t n = ids.size();
     if (!have_ublk || dirty_upper_lost || d_upper_base.cap == 0 || h_upper_base.size() < upper_slots || upper_slots > n) return false;
+    if (dirty_upper.size() > 64 * (h_udesc.size() + 64)) return false;      // a builder round: not worth sorting
     std::sort(dirty_upper.begin(), dirty_upper.end());
     dirty_upper.erase(std::unique(dirty_upper.begin(), dirty_upper.end()), dirty_upper.end());
     if (dirty_upper.size() * 8 > h_udesc.size() + 64 || pool_used > 2 * pool_live + (size_t(1) << 20)) return false;
