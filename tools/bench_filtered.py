@@ -35,7 +35,10 @@ def build(mode):
     seg = vdb.Segment(vdb.HNSWIndex(vdb.DistanceMetric(args.metric), 16, 64, 16, D, seed=0xC4, filter_mode=mode))
     t0 = time.perf_counter()
     CH = 100_000
-    got = [seg.insert_batch(base[lo:lo + CH], payloads[lo:lo + CH]) for lo in range(0, N, CH)]
+    got = []
+    for lo in range(0, N, CH):
+        got.append(seg.insert_batch(base[lo:lo + CH], payloads[lo:lo + CH]))
+        print(f"[filtered] {mode.name}: {min(N, lo + CH)} points in {time.perf_counter() - t0:.1f}s", file=sys.stderr, flush=True)
     assert np.array_equal(np.concatenate(got), ids + np.uint64(FIRST_ID)), "segment ids are expected to run from FIRST_ID"
     print(f"[filtered] {mode.name}: segment of {N} built in {time.perf_counter() - t0:.1f}s (payload objects: {t_payload:.1f}s)", file=sys.stderr)
     return seg
