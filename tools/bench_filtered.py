@@ -25,6 +25,7 @@ FIRST_ID = 1          # Segment ids start at 1 (segment.rs:27)
 cat = (ids % 100).astype(np.int64)
 tier = (((ids * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(40)) % np.uint64(10)).astype(np.int64)
 
+print(f"[filtered] {N} x {D} rows generated", file=sys.stderr, flush=True)
 t0 = time.perf_counter()
 payloads = []
 for i in range(N):
@@ -59,7 +60,10 @@ def ground_truth(mask):
     top = np.argpartition(dist, K, axis=1)[:, :K]
     return [set(rows[t].tolist()) for t in top]
 
-truths = [ground_truth(mask) for _, _, mask in cases]
+truths = []
+for name, _, mask in cases:
+    truths.append(ground_truth(mask))
+    print(f"[filtered] ground truth for {name}: done", file=sys.stderr, flush=True)
 for mode in [m for m in (vdb.FilterMode.Masked, vdb.FilterMode.Literal) if m.name.lower() in args.modes.split(",")]:
     seg = build(mode)
     for (name, make, mask), truth in zip(cases, truths):
