@@ -220,7 +220,9 @@ vdb_status vdb_index_exact_knn_batch(const vdb_index* x, const float* queries, s
 vdb_status vdb_index_exact_knn_batch_dev(const vdb_index* x, const float* d_queries, size_t nq, size_t top_k,
                                          vdb_scored_point* d_out, uint32_t* d_out_n, void* stream);
 
-vdb_status vdb_index_mark_deleted(vdb_index* x, uint64_t id);                    /* hnsw.rs:111-117 */
+/* hnsw.rs:111-117.  An id the index does not hold is remembered (the reference's HashSet takes any
+ * id, hnsw.rs:112): a point inserted under it later is a tombstone from birth. */
+vdb_status vdb_index_mark_deleted(vdb_index* x, uint64_t id);
 int    vdb_index_contains(const vdb_index* x, uint64_t id);                      /* hnsw.rs:691-693 */
 size_t vdb_index_len(const vdb_index* x);                                        /* hnsw.rs:695-697 */
 int    vdb_index_metric(const vdb_index* x);                                     /* hnsw.rs:707-709 */
@@ -252,9 +254,13 @@ vdb_status vdb_index_greedy_search_layer_unfiltered(const vdb_index* x, const fl
  * (the "reference-built graph" of the north-star path); export returns the literal lists.
  *   ids[n], levels[n], vectors[n*dim] (stored form), deleted[n] (0/1, may be NULL),
  *   per layer l in [0, n_layers): owners (slot indices that own a list at l), offsets
- *   (len owners+1) into a flat neighbour array of slot indices. */
+ *   (len owners+1) into a flat neighbour array of slot indices.
+ * Everything is validated before the index is touched (ids distinct, owners distinct per layer and
+ * below n, offsets as described at vdb_layer_csr, neighbours below n, entry id known): a bad graph
+ * is VDB_ERR_ARGUMENT and leaves the index as it was. */
 typedef struct {
     size_t n_lists; const uint32_t* owners; const uint64_t* offsets; const uint32_t* neighbors;
+    size_t n_edges;      /* length of `neighbors`; offsets[0] == 0, offsets ascend, offsets[n_lists] == n_edges */
 } vdb_layer_csr;
 vdb_status vdb_index_import_graph(vdb_index* x, size_t n, const uint64_t* ids, const uint32_t* levels,
                                   const float* vectors, const uint8_t* deleted,
@@ -273,7 +279,10 @@ vdb_status vdb_index_export_layer(const vdb_index* x, size_t level, uint32_t* ow
  *   u64 ids[n]; u32 levels[n]; u8 deleted[n]; f32 vectors[n * dim] (stored form)
  *   per layer: u64 n_lists, n_edges; u32 owners[n_lists]; u64 offsets[n_lists + 1];
  *     u32 neighbors[n_edges]                       (the arrays of vdb_index_export_layer)
- * load replaces the contents of an index created with the same metric and dimension. */
+ * load replaces the contents of an index created with the same metric and dimension and takes over
+ * the file's seed and stream positions, so that inserts after a load continue the saved build.
+ * A file that cannot be opened, read or written is VDB_ERR_IO; one whose contents are inconsistent
+ * is VDB_ERR_ARGUMENT and leaves the index as it was. */
 vdb_status vdb_index_save(const vdb_index* x, const char* path);
 vdb_status vdb_index_load(vdb_index* x, const char* path);
 /* Device-side footprint of the packed graph actually searched (after self-loop / duplicate removal). */

@@ -21,7 +21,7 @@ int fail_arg(const char* m) { g_err = m; return 101; }
 struct scored_point_c { uint64_t id; float raw_score; float sort_key; };
 struct query_stats_c { uint32_t rows_scored, expanded, adj_entries, flags; };
 struct options_c { uint64_t seed; int32_t device, arith, filter_mode, reserved; };
-struct layer_csr_c { size_t n_lists; const uint32_t* owners; const uint64_t* offsets; const uint32_t* neighbors; };
+struct layer_csr_c { size_t n_lists; const uint32_t* owners; const uint64_t* offsets; const uint32_t* neighbors; size_t n_edges; };
 
 int emit(const std::vector<ScoredPoint>& v, scored_point_c* out, size_t* out_n) {
     for (size_t i = 0; i < v.size(); ++i) out[i] = {v[i].id, v[i].raw_score, v[i].sort_key};

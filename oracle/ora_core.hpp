@@ -487,6 +487,7 @@ struct HNSWIndex {
     std::vector<Layer> layers;          // layers[l].idx[slot] = list index or -1 (absent)
     std::vector<uint8_t> deleted; size_t n_deleted = 0;
     std::set<PointId> live;             // DET-1: "first non-deleted key" == smallest live id
+    std::set<PointId> pending_deleted;  // ids marked deleted before they were inserted (hnsw.rs:112 takes any id)
     uint64_t seed = 0, level_draws = 0, sample_draws = 0;
     static Scratch& tls_scratch() { static thread_local Scratch sc; return sc; }
 
@@ -542,7 +543,8 @@ struct HNSWIndex {
     // hnsw.rs:111-117
     void mark_deleted(PointId id) {
         auto it = slot_of.find(id);
-        // HashSet::insert accepts unknown ids too; they can only matter through entry_point equality.
+        // HashSet::insert accepts unknown ids too (hnsw.rs:112): a point inserted under such an id later is deleted from birth.
+        if (it == slot_of.end()) pending_deleted.insert(id);
         if (it != slot_of.end() && !deleted[it->second]) { deleted[it->second] = 1; ++n_deleted; live.erase(id); }
         if (entry_point && *entry_point == id) {
             if (live.empty()) entry_point = std::nullopt; else entry_point = *live.begin();
@@ -616,7 +618,8 @@ struct HNSWIndex {
         std::vector<float> nv = maybe_normalize(v);
         uint32_t s = (uint32_t)ids.size();
         ids.push_back(id); slot_of[id] = s; vecs.insert(vecs.end(), nv.begin(), nv.end());
-        levels.push_back(level); deleted.push_back(0); live.insert(id);
+        levels.push_back(level);
+        if (pending_deleted.erase(id)) { deleted.push_back(1); ++n_deleted; } else { deleted.push_back(0); live.insert(id); }
         for (size_t l = 0; l <= level; ++l) list_or_default(l, s).push_back(s);  // :143-148
         if (!entry_point) { entry_point = id; current_max_level = level; return Result<bool>::good(true); }
         uint32_t ep = slot_of.at(*entry_point);

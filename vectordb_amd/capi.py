@@ -107,7 +107,8 @@ class OptionsC(C.Structure):
 
 
 class LayerCsrC(C.Structure):
-    _fields_ = [("n_lists", C.c_size_t), ("owners", C.c_void_p), ("offsets", C.c_void_p), ("neighbors", C.c_void_p)]
+    _fields_ = [("n_lists", C.c_size_t), ("owners", C.c_void_p), ("offsets", C.c_void_p), ("neighbors", C.c_void_p),
+                ("n_edges", C.c_size_t)]
 
 
 class ScoredPoint:
@@ -495,7 +496,7 @@ def bind(cdll, prefix="vdb_", required=None):
             for l, (ow, of, nb) in enumerate(g["layers"]):
                 ow = np.ascontiguousarray(ow, np.uint32); of = np.ascontiguousarray(of, np.uint64)
                 nb = np.ascontiguousarray(nb, np.uint32); keep += [ow, of, nb]
-                arr[l] = LayerCsrC(len(ow), ow.ctypes.data, of.ctypes.data, nb.ctypes.data)
+                arr[l] = LayerCsrC(len(ow), ow.ctypes.data, of.ctypes.data, nb.ctypes.data, len(nb))
             e = g["entry"]
             check(fn.index_import_graph(self._h, len(ids), _ptr(ids), _ptr(lv), _ptr(vec), _ptr(dl), len(g["layers"]),
                                         C.cast(arr, _VP), 0 if e is None else 1, 0 if e is None else e,

@@ -450,7 +450,7 @@ vdb_status vdb_segment_in_place_filtered_search(const vdb_segment* s, const floa
     return guard([&] { need(s, "segment"); need(q, "query"); emit(s->in_place_filtered_search(q, len, top_k, f), out, out_n); });
 }
 vdb_status vdb_segment_compile_filter(const vdb_segment* s, const vdb_filter* f, size_t* n_pass, size_t* n_err) {
-    return guard([&] { need(s, "segment"); need(f, "filter"); const FilterBits& b = s->compile(*f); if (n_pass) *n_pass = b.n_pass; if (n_err) *n_err = b.n_err; });
+    return guard([&] { need(s, "segment"); need(f, "filter"); const auto b = s->compile(*f); if (n_pass) *n_pass = b->n_pass; if (n_err) *n_err = b->n_err; });
 }
 
 // ---- scale-out ----

@@ -46,6 +46,7 @@ struct FilterBits {                      // a Filter compiled against the segmen
     DevBuf<uint32_t> d_pass, d_err;
     size_t n_pass = 0, n_err = 0; uint64_t version = 0;
     std::vector<uint32_t> live_pass;     // passing slots that are not tombstoned, ascending
+    uint64_t last_used = 0;              // cache clock of the segment (least recently used entries are dropped)
 };
 
 }  // namespace vdb
@@ -153,7 +154,13 @@ struct vdb_segment {
     std::unique_ptr<vdb_index> hnsw; vdb_payload_index payload_index;
     std::unordered_map<uint64_t, vdb_payload> payloads; std::set<uint64_t> deleted; uint64_t next_id = 1;   // segment.rs:21-29
     uint64_t payload_version = 1;
-    mutable std::map<std::string, std::unique_ptr<vdb::FilterBits>> filter_cache;
+    // Compiled filters by canonical text.  Searches are const and may run from several host threads: the cache is
+    // guarded by filter_mu, every entry is built as a new object and handed out as a shared pointer, so a search
+    // keeps its bitmaps alive while another thread replaces or evicts the entry.  At most FILTER_CACHE_MAX entries.
+    static constexpr size_t FILTER_CACHE_MAX = 16;
+    mutable std::mutex filter_mu;
+    mutable std::map<std::string, std::shared_ptr<vdb::FilterBits>> filter_cache;
+    mutable uint64_t filter_clock = 0;
 
     explicit vdb_segment(vdb_index* h) : hnsw(h) {}
     uint64_t insert(const float* v, size_t len, const vdb_payload* p);
@@ -168,7 +175,7 @@ struct vdb_segment {
     std::vector<vdb_scored_point> in_place_filtered_search(const float* q, size_t len, size_t top_k, const vdb_filter* f) const;
     void search_batch(const float* q, size_t nq, size_t len, size_t top_k, size_t ef_search, const vdb_filter* f,
                       vdb_scored_point* out, uint32_t* out_n) const;
-    const vdb::FilterBits& compile(const vdb_filter& f) const;
+    std::shared_ptr<const vdb::FilterBits> compile(const vdb_filter& f) const;
     void build_filter_aware_edges(uint64_t id, const vdb_payload& p, const std::vector<std::string>& keys);
     void filter_aware_edges_batch(const std::vector<uint64_t>& pids, const vdb_payload* const* p);
 

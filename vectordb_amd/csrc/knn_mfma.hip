@@ -22,6 +22,38 @@ constexpr int MT = 32;             // base rows per tile (the M side)
 template <int KP> struct KnnBuf { static constexpr int CAP = KP == 16 ? 40 : 64, TRIG = CAP - 16; };
 constexpr float INF_F = __builtin_inff();
 
+// Keeps the KP smallest entries of query `qi`'s candidate buffer, ordered by (ranking key, PointId) — the order of
+// the final result, so rows that tie exactly (repeated vectors) survive by id whatever their slots are.  All lanes of
+// the wave take part; returns the new admission bound: key and id of the KP-th entry once KP are held, else (+inf, 0).
+template <int KP, int CAP>
+__device__ __forceinline__ void knn_compact(const GraphView& gv, uint32_t* cnt, uint2* buf, uint32_t qi, float& thr, uint64_t& thr_id) {
+    const int lane = lane_id();
+    const uint32_t n = __builtin_amdgcn_readfirstlane(cnt[qi]);
+    uint2 e = make_uint2(0x7f800000u, 0xFFFFFFFFu);
+    uint64_t id = ~0ull;
+    if ((uint32_t)lane < n) { e = buf[qi * CAP + lane]; id = gv.ids[e.y]; }
+    const float k = __uint_as_float(e.x);
+    const uint32_t id_lo = (uint32_t)id, id_hi = (uint32_t)(id >> 32);
+    uint32_t rank = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float ki = readlane_f(k, (int)i);
+        const uint64_t ii = ((uint64_t)readlane_u(id_hi, (int)i) << 32) | readlane_u(id_lo, (int)i);
+        rank += (ki < k || (ki == k && ii < id)) ? 1u : 0u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if ((uint32_t)lane < n && rank < KP) buf[qi * CAP + rank] = e;
+    const uint32_t kept = n < KP ? n : KP;
+    if (lane == 0) cnt[qi] = kept;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const uint64_t last = __ballot((uint32_t)lane < n && rank == KP - 1);
+    thr = INF_F; thr_id = 0;
+    if (last) {
+        const int l = __ffsll((unsigned long long)last) - 1;
+        thr = readlane_f(k, l);
+        thr_id = ((uint64_t)readlane_u(id_hi, l) << 32) | readlane_u(id_lo, l);
+    }
+}
+
 // scale / bias turn a dot product into the ranking key: key = dot * scale[row] + bias[row].
 __global__ void __launch_bounds__(256) knn_prepare_kernel(GraphView gv, float* __restrict__ scale, float* __restrict__ bias) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -73,7 +105,7 @@ __global__ void __launch_bounds__(256) knn_mfma_kernel(GraphView gv, const float
         b[s] = (q < nq && d < dim) ? queries[(size_t)q * dim + d] : 0.f;
     }
     if (tid < MQ) cnt[tid] = 0;
-    float thr = INF_F;
+    float thr = INF_F; uint64_t thr_id = 0;      // admission bound of this lane's query: (key, id) of its KP-th candidate
 
     const uint32_t per = (((gv.n + n_chunks - 1) / n_chunks) + MT - 1) / MT * MT;
     const uint32_t r_begin = blockIdx.x * per, r_end = min(gv.n, r_begin + per);
@@ -98,26 +130,6 @@ __global__ void __launch_bounds__(256) knn_mfma_kernel(GraphView gv, const float
         if (tid < MT) { sc_t[tid] = st_sc; bi_t[tid] = st_bi; }
     };
 
-    // keeps the KNN_KP smallest (key, row) of query `qi`'s buffer; all lanes of the wave take part
-    auto compact = [&](uint32_t qi) -> float {
-        const uint32_t n = __builtin_amdgcn_readfirstlane(cnt[qi]);
-        uint2 e = make_uint2(0x7f800000u, 0xFFFFFFFFu);
-        if ((uint32_t)lane < n) e = buf[qi * KNN_CAP + lane];
-        const float k = __uint_as_float(e.x);
-        uint32_t rank = 0;
-        for (uint32_t i = 0; i < n; ++i) {
-            const float ki = readlane_f(k, (int)i); const uint32_t ri = readlane_u(e.y, (int)i);
-            rank += (ki < k || (ki == k && ri < e.y)) ? 1u : 0u;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if ((uint32_t)lane < n && rank < KNN_KP) buf[qi * KNN_CAP + rank] = e;
-        const uint32_t kept = n < KNN_KP ? n : KNN_KP;
-        if (lane == 0) cnt[qi] = kept;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // new threshold: the largest kept key once KNN_KP are held
-        const uint64_t last = __ballot((uint32_t)lane < n && rank == KNN_KP - 1);
-        return last ? readlane_f(k, __ffsll((unsigned long long)last) - 1) : INF_F;
-    };
 
     if (r_begin < r_end) fetch(r_begin);
     for (uint32_t tb = r_begin; tb < r_end; tb += MT) {
@@ -155,15 +167,16 @@ __global__ void __launch_bounds__(256) knn_mfma_kernel(GraphView gv, const float
         for (int hv = 0; hv < 2; ++hv) {           // rows in two halves: at most 16 pushes per query between compactions
             bool any2 = false;
 #pragma unroll
-            for (int v = hv * 8; v < hv * 8 + 8; ++v) any2 = any2 || key[v] < thr;
+            for (int v = hv * 8; v < hv * 8 + 8; ++v) any2 = any2 || key[v] <= thr;
             if (q >= nq) any2 = false;
             if (__ballot(any2)) {
                 if (any2) {
 #pragma unroll
                     for (int v = hv * 8; v < hv * 8 + 8; ++v) {
-                        if (key[v] < thr) {
+                        const uint32_t row = tb + (v / 4) * 8 + h * 4 + (v % 4);
+                        if (key[v] < thr || (key[v] == thr && thr_id != 0 && gv.ids[row] < thr_id)) {
                             const uint32_t pos = atomicAdd(&cnt[ql], 1u);
-                            buf[ql * KNN_CAP + pos] = make_uint2(__float_as_uint(key[v]), tb + (v / 4) * 8 + h * 4 + (v % 4));
+                            buf[ql * KNN_CAP + pos] = make_uint2(__float_as_uint(key[v]), row);
                         }
                     }
                 }
@@ -172,8 +185,9 @@ __global__ void __launch_bounds__(256) knn_mfma_kernel(GraphView gv, const float
                 uint64_t need = __ballot(lane < 32 && cnt[wave * 32 + (lane & 31)] > KNN_TRIG);
                 while (need) {
                     const int jj = __ffsll((unsigned long long)need) - 1; need &= need - 1;
-                    const float nt = compact(wave * 32 + jj);
-                    if (j == jj) thr = nt;
+                    float nt; uint64_t ni;
+                    knn_compact<KNN_KP, KNN_CAP>(gv, cnt, buf, wave * 32 + jj, nt, ni);
+                    if (j == jj) { thr = nt; thr_id = ni; }
                 }
             }
         }
@@ -183,7 +197,7 @@ __global__ void __launch_bounds__(256) knn_mfma_kernel(GraphView gv, const float
     for (int jj = 0; jj < 32; ++jj) {
         const uint32_t qi = wave * 32 + jj, qg = blockIdx.y * MQ + qi;
         if (qg >= nq) break;
-        if (cnt[qi] > KNN_KP) compact(qi);
+        if (cnt[qi] > KNN_KP) { float nt; uint64_t ni; knn_compact<KNN_KP, KNN_CAP>(gv, cnt, buf, qi, nt, ni); }
         const uint32_t n = cnt[qi];
         if (lane < KNN_KP) out_slots[((size_t)qg * n_chunks + blockIdx.x) * KNN_KP + lane] = (uint32_t)lane < n ? buf[qi * KNN_CAP + lane].y : NONE32;
     }
@@ -219,29 +233,11 @@ __global__ void __launch_bounds__(256) knn_mfma_long_kernel(GraphView gv, const 
     const uint32_t nkc = (stride + KC - 1) / KC;
 
     if (tid < MQ) cnt[tid] = 0;
-    float thr = INF_F;
+    float thr = INF_F; uint64_t thr_id = 0;      // admission bound of this lane's query: (key, id) of its KP-th candidate
     const uint32_t per = (((gv.n + n_chunks - 1) / n_chunks) + LT - 1) / LT * LT;
     const uint32_t r_begin = blockIdx.x * per, r_end = min(gv.n, r_begin + per);
     const int lrow = tid >> 1, lhalf = tid & 1;          // loader: thread t brings 16 floats of tile row t / 2
 
-    auto compact = [&](uint32_t qi) -> float {
-        const uint32_t n = __builtin_amdgcn_readfirstlane(cnt[qi]);
-        uint2 e = make_uint2(0x7f800000u, 0xFFFFFFFFu);
-        if ((uint32_t)lane < n) e = buf[qi * KNN_CAP + lane];
-        const float k = __uint_as_float(e.x);
-        uint32_t rank = 0;
-        for (uint32_t i = 0; i < n; ++i) {
-            const float ki = readlane_f(k, (int)i); const uint32_t ri = readlane_u(e.y, (int)i);
-            rank += (ki < k || (ki == k && ri < e.y)) ? 1u : 0u;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if ((uint32_t)lane < n && rank < KNN_KP) buf[qi * KNN_CAP + rank] = e;
-        const uint32_t kept = n < KNN_KP ? n : KNN_KP;
-        if (lane == 0) cnt[qi] = kept;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const uint64_t last = __ballot((uint32_t)lane < n && rank == KNN_KP - 1);
-        return last ? readlane_f(k, __ffsll((unsigned long long)last) - 1) : INF_F;
-    };
 
     for (uint32_t tb = r_begin; tb < r_end; tb += LT) {
         float4 stage[4]; float bq[16], bn[16];
@@ -317,15 +313,16 @@ __global__ void __launch_bounds__(256) knn_mfma_long_kernel(GraphView gv, const 
             for (int hv = 0; hv < 2; ++hv) {
                 bool any2 = false;
 #pragma unroll
-                for (int v = hv * 8; v < hv * 8 + 8; ++v) any2 = any2 || key[v] < thr;
+                for (int v = hv * 8; v < hv * 8 + 8; ++v) any2 = any2 || key[v] <= thr;
                 if (!qin) any2 = false;
                 if (__ballot(any2)) {
                     if (any2) {
 #pragma unroll
                         for (int v = hv * 8; v < hv * 8 + 8; ++v) {
-                            if (key[v] < thr) {
+                            const uint32_t row = tb + t * 32 + (v / 4) * 8 + h * 4 + (v % 4);
+                            if (key[v] < thr || (key[v] == thr && thr_id != 0 && gv.ids[row] < thr_id)) {
                                 const uint32_t pos = atomicAdd(&cnt[ql], 1u);
-                                buf[ql * KNN_CAP + pos] = make_uint2(__float_as_uint(key[v]), tb + t * 32 + (v / 4) * 8 + h * 4 + (v % 4));
+                                buf[ql * KNN_CAP + pos] = make_uint2(__float_as_uint(key[v]), row);
                             }
                         }
                     }
@@ -333,8 +330,9 @@ __global__ void __launch_bounds__(256) knn_mfma_long_kernel(GraphView gv, const 
                     uint64_t need = __ballot(lane < 32 && cnt[wave * 32 + (lane & 31)] > KNN_TRIG);
                     while (need) {
                         const int jj = __ffsll((unsigned long long)need) - 1; need &= need - 1;
-                        const float nt = compact(wave * 32 + jj);
-                        if (j == jj) thr = nt;
+                        float nt; uint64_t ni;
+                        knn_compact<KNN_KP, KNN_CAP>(gv, cnt, buf, wave * 32 + jj, nt, ni);
+                        if (j == jj) { thr = nt; thr_id = ni; }
                     }
                 }
             }
@@ -344,7 +342,7 @@ __global__ void __launch_bounds__(256) knn_mfma_long_kernel(GraphView gv, const 
     for (int jj = 0; jj < 32; ++jj) {
         const uint32_t qi = wave * 32 + jj, qg = blockIdx.y * MQ + qi;
         if (qg >= nq) break;
-        if (cnt[qi] > KNN_KP) compact(qi);
+        if (cnt[qi] > KNN_KP) { float nt; uint64_t ni; knn_compact<KNN_KP, KNN_CAP>(gv, cnt, buf, qi, nt, ni); }
         const uint32_t n = cnt[qi];
         if (lane < KNN_KP) out_slots[((size_t)qg * n_chunks + blockIdx.x) * KNN_KP + lane] = (uint32_t)lane < n ? buf[qi * KNN_CAP + lane].y : NONE32;
     }

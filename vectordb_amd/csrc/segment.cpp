@@ -301,7 +301,7 @@ void vdb_segment::purge() {                                                     
     }
     hnsw = std::move(nh); payload_index = std::move(npi); payloads = std::move(npl);
     deleted.clear();
-    filter_cache.clear();
+    { std::lock_guard<std::mutex> lk(filter_mu); filter_cache.clear(); }
     ++payload_version;
 }
 
@@ -334,13 +334,18 @@ std::optional<uint64_t> vdb_segment::find_entry_point_matching_filter(const vdb_
 
 // Predicate -> per-slot bitmaps: pass (filter true) and err (evaluate_filter returned Err).  A slot
 // without a payload has neither bit (hnsw.rs:669 map_or(false), :391 continue).
-const FilterBits& vdb_segment::compile(const vdb_filter& f) const {
+std::shared_ptr<const FilterBits> vdb_segment::compile(const vdb_filter& f) const {
     std::string key; f.serialise(key);
-    auto& slot = filter_cache[key];
     const size_t n = hnsw->len();
-    if (slot && slot->version == payload_version && slot->pass.size() == (n + 31) / 32) return *slot;
-    if (!slot) slot = std::make_unique<FilterBits>();
-    FilterBits& fb = *slot;
+    // one compilation at a time: two threads that ask for the same new filter get the same object
+    std::lock_guard<std::mutex> lk(filter_mu);
+    auto it = filter_cache.find(key);
+    if (it != filter_cache.end() && it->second->version == payload_version && it->second->pass.size() == (n + 31) / 32) {
+        it->second->last_used = ++filter_clock;
+        return it->second;
+    }
+    auto fresh = std::make_shared<FilterBits>();
+    FilterBits& fb = *fresh;
     fb.pass.assign((n + 31) / 32, 0); fb.err.assign((n + 31) / 32, 0); fb.n_pass = fb.n_err = 0; fb.live_pass.clear();
     for (size_t s = 0; s < n; ++s) {
         auto pit = payloads.find(hnsw->ids[s]);
@@ -349,16 +354,29 @@ const FilterBits& vdb_segment::compile(const vdb_filter& f) const {
         if (t.s == Tri::True) { fb.pass[s >> 5] |= 1u << (s & 31); if (!hnsw->deleted[s]) { ++fb.n_pass; fb.live_pass.push_back((uint32_t)s); } }
         else if (t.s == Tri::Err) { fb.err[s >> 5] |= 1u << (s & 31); if (!hnsw->deleted[s]) ++fb.n_err; }
     }
-    hnsw->use_device();
-    const size_t w = std::max<size_t>(fb.pass.size(), 1);
-    fb.d_pass.reserve(w, hnsw->stream, false); fb.d_err.reserve(w, hnsw->stream, false);
-    if (!fb.pass.empty()) {
-        VDB_HIP(hipMemcpyAsync(fb.d_pass.p, fb.pass.data(), fb.pass.size() * 4, hipMemcpyHostToDevice, hnsw->stream));
-        VDB_HIP(hipMemcpyAsync(fb.d_err.p, fb.err.data(), fb.err.size() * 4, hipMemcpyHostToDevice, hnsw->stream));
-        VDB_HIP(hipStreamSynchronize(hnsw->stream));
+    {
+        std::lock_guard<std::mutex> dl(hnsw->mu);              // the index's stream is shared with its searches
+        hnsw->use_device();
+        const size_t w = std::max<size_t>(fb.pass.size(), 1);
+        fb.d_pass.reserve(w, hnsw->stream, false); fb.d_err.reserve(w, hnsw->stream, false);
+        if (!fb.pass.empty()) {
+            VDB_HIP(hipMemcpyAsync(fb.d_pass.p, fb.pass.data(), fb.pass.size() * 4, hipMemcpyHostToDevice, hnsw->stream));
+            VDB_HIP(hipMemcpyAsync(fb.d_err.p, fb.err.data(), fb.err.size() * 4, hipMemcpyHostToDevice, hnsw->stream));
+            VDB_HIP(hipStreamSynchronize(hnsw->stream));
+        }
     }
     fb.version = payload_version;
-    return fb;
+    fb.last_used = ++filter_clock;
+    if (it != filter_cache.end()) it->second = fresh;          // a stale entry: searches still using it keep their reference
+    else {
+        while (filter_cache.size() >= FILTER_CACHE_MAX) {      // drop the least recently used entry
+            auto victim = filter_cache.begin();
+            for (auto c = filter_cache.begin(); c != filter_cache.end(); ++c) if (c->second->last_used < victim->second->last_used) victim = c;
+            filter_cache.erase(victim);
+        }
+        filter_cache.emplace(std::move(key), fresh);
+    }
+    return fresh;
 }
 
 // Masked mode: when at most this fraction of the rows passes, the passing rows are scanned exactly
@@ -374,8 +392,8 @@ void vdb_segment::filtered_batch(const float* q, size_t nq, size_t len, size_t t
     vdb_index& h = *hnsw;
     if (len != h.dim) throw Failure(err_length_mismatch(h.dim, len));               // hnsw.rs:593-598
     vdb_index::FilterArgs fa;
-    const FilterBits* bits = f ? &compile(*f) : nullptr;
-    fa.bits = bits;
+    const std::shared_ptr<const FilterBits> bits = f ? compile(*f) : nullptr;     // alive until this call returns
+    fa.bits = bits.get();
     if (h.opts.filter_mode == VDB_FILTER_MASKED) {
         if (f && masked_scan_pays(bits->n_pass, h.len())) {
             // the scan returns no tombstone, so the caller's over-fetch is not needed; rows of out stay top_k apart
