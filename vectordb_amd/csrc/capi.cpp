@@ -30,6 +30,7 @@ vdb_status tri_out(const Tri& t, int* out) {
     *out = t.s == Tri::True; return VDB_OK;
 }
 vdb_value* mk(ValueData d) { auto* v = new vdb_value; v->d = std::move(d); return v; }
+template <class T> T* null_arg(const char* what) { set_last_error(std::string(what) + " is NULL"); return nullptr; }
 }  // namespace
 
 extern "C" {
@@ -89,20 +90,29 @@ vdb_value* vdb_value_int(int64_t v) { return mk(v); }
 vdb_value* vdb_value_float(double v) { return mk(OF64{v}); }
 vdb_value* vdb_value_str(const char* s, size_t len) { return mk(std::string(s ? s : "", s ? len : 0)); }
 vdb_value* vdb_value_bool(int v) { return mk(Bool8{(uint8_t)(v != 0)}); }
-vdb_value* vdb_value_list_int(const int64_t* v, size_t n) { return mk(std::vector<int64_t>(v, v + n)); }
-vdb_value* vdb_value_list_float(const double* v, size_t n) { std::vector<OF64> l(n); for (size_t i = 0; i < n; ++i) l[i].v = v[i]; return mk(std::move(l)); }
-vdb_value* vdb_value_list_str(const char* const* s, const size_t* lens, size_t n) {
-    std::vector<std::string> l; for (size_t i = 0; i < n; ++i) l.emplace_back(s[i], lens[i]); return mk(std::move(l));
+// constructors return NULL (with the reason in vdb_last_error_message) when handed a NULL array of n > 0 elements
+vdb_value* vdb_value_list_int(const int64_t* v, size_t n) { if (n && !v) return null_arg<vdb_value>("v"); return mk(std::vector<int64_t>(v, v + n)); }
+vdb_value* vdb_value_list_float(const double* v, size_t n) {
+    if (n && !v) return null_arg<vdb_value>("v");
+    std::vector<OF64> l(n); for (size_t i = 0; i < n; ++i) l[i].v = v[i]; return mk(std::move(l));
 }
-vdb_value* vdb_value_list_bool(const uint8_t* v, size_t n) { std::vector<Bool8> l(n); for (size_t i = 0; i < n; ++i) l[i].v = v[i] != 0; return mk(std::move(l)); }
+vdb_value* vdb_value_list_str(const char* const* s, const size_t* lens, size_t n) {
+    if (n && (!s || !lens)) return null_arg<vdb_value>("s / lens");
+    for (size_t i = 0; i < n; ++i) if (!s[i] && lens[i]) return null_arg<vdb_value>("s[i]");
+    std::vector<std::string> l; for (size_t i = 0; i < n; ++i) l.emplace_back(s[i] ? s[i] : "", lens[i]); return mk(std::move(l));
+}
+vdb_value* vdb_value_list_bool(const uint8_t* v, size_t n) {
+    if (n && !v) return null_arg<vdb_value>("v");
+    std::vector<Bool8> l(n); for (size_t i = 0; i < n; ++i) l[i].v = v[i] != 0; return mk(std::move(l));
+}
 void vdb_value_free(vdb_value* v) { delete v; }
-int vdb_value_type(const vdb_value* v) { return v->kind(); }
-int vdb_value_equals(const vdb_value* a, const vdb_value* b) { return *a == *b; }
+int vdb_value_type(const vdb_value* v) { if (!v) { set_last_error("value is NULL"); return -1; } return v->kind(); }
+int vdb_value_equals(const vdb_value* a, const vdb_value* b) { if (!a || !b) { set_last_error("value is NULL"); return 0; } return *a == *b; }
 vdb_status vdb_value_compare_scalar(const vdb_value* a, vdb_cmp_op op, const vdb_value* b, int* is_some, int* out) {
-    return guard([&] { need(a, "a"); need(b, "b"); auto r = compare_scalar(*a, op, *b); *is_some = r.has_value(); *out = r.value_or(false); });
+    return guard([&] { need(a, "a"); need(b, "b"); need(is_some, "is_some"); need(out, "out"); auto r = compare_scalar(*a, op, *b); *is_some = r.has_value(); *out = r.value_or(false); });
 }
 vdb_status vdb_value_evaluate_list_query(const vdb_value* self, vdb_list_query kind, vdb_cmp_op op, size_t n, const vdb_value* v, int* is_some, int* out) {
-    return guard([&] { need(self, "self"); auto r = evaluate_list_query(*self, kind, op, n, v); *is_some = r.has_value(); *out = r.value_or(false); });
+    return guard([&] { need(self, "self"); need(is_some, "is_some"); need(out, "out"); auto r = evaluate_list_query(*self, kind, op, n, v); *is_some = r.has_value(); *out = r.value_or(false); });
 }
 vdb_payload* vdb_payload_new(void) { return new vdb_payload; }
 void vdb_payload_free(vdb_payload* p) { delete p; }
@@ -118,13 +128,22 @@ vdb_status vdb_payload_evaluate_list_field(const vdb_payload* p, const char* fie
 }
 
 // ---- filters.rs ----
-vdb_filter* vdb_filter_match(const char* key, const vdb_value* v) { auto* f = new vdb_filter; f->kind = vdb_filter::Match; f->key = key; f->value = *v; return f; }
+vdb_filter* vdb_filter_match(const char* key, const vdb_value* v) {
+    if (!key || !v) return null_arg<vdb_filter>("key / value");
+    auto* f = new vdb_filter; f->kind = vdb_filter::Match; f->key = key; f->value = *v; return f;
+}
 vdb_filter* vdb_filter_compare(const char* key, vdb_cmp_op op, const vdb_value* v) {
+    if (!key || !v) return null_arg<vdb_filter>("key / value");
     auto* f = new vdb_filter; f->kind = vdb_filter::Compare; f->key = key; f->op = op; f->value = *v; return f;
 }
-vdb_filter* vdb_filter_and(const vdb_filter* const* c, size_t n) { auto* f = new vdb_filter; f->kind = vdb_filter::And; for (size_t i = 0; i < n; ++i) f->kids.push_back(*c[i]); return f; }
-vdb_filter* vdb_filter_or(const vdb_filter* const* c, size_t n) { auto* f = new vdb_filter; f->kind = vdb_filter::Or; for (size_t i = 0; i < n; ++i) f->kids.push_back(*c[i]); return f; }
-vdb_filter* vdb_filter_not(const vdb_filter* c) { auto* f = new vdb_filter; f->kind = vdb_filter::Not; f->kids.push_back(*c); return f; }
+static vdb_filter* nary(vdb_filter::Kind kind, const vdb_filter* const* c, size_t n) {
+    if (n && !c) return null_arg<vdb_filter>("children");
+    for (size_t i = 0; i < n; ++i) if (!c[i]) return null_arg<vdb_filter>("children[i]");
+    auto* f = new vdb_filter; f->kind = kind; for (size_t i = 0; i < n; ++i) f->kids.push_back(*c[i]); return f;
+}
+vdb_filter* vdb_filter_and(const vdb_filter* const* c, size_t n) { return nary(vdb_filter::And, c, n); }
+vdb_filter* vdb_filter_or(const vdb_filter* const* c, size_t n) { return nary(vdb_filter::Or, c, n); }
+vdb_filter* vdb_filter_not(const vdb_filter* c) { if (!c) return null_arg<vdb_filter>("child"); auto* f = new vdb_filter; f->kind = vdb_filter::Not; f->kids.push_back(*c); return f; }
 void vdb_filter_free(vdb_filter* f) { delete f; }
 vdb_status vdb_filter_evaluate(const vdb_filter* f, const vdb_payload* p, int* out) {
     if (!f || !p || !out) { set_last_error("NULL argument"); return VDB_ERR_ARGUMENT; }
@@ -325,17 +344,21 @@ struct GraphFileHeader {
 static_assert(sizeof(GraphFileHeader) == 112, "graph file header is 112 bytes");
 struct File {
     FILE* f; std::string path;
-    File(const char* p, const char* mode) : f(std::fopen(p, mode)), path(p) { if (!f) throw Failure(err_arg("cannot open " + path)); }
+    File(const char* p, const char* mode) : f(std::fopen(p, mode)), path(p) { if (!f) throw Failure(err_io("cannot open " + path)); }
     ~File() { if (f) std::fclose(f); }
     void put(const void* d, size_t bytes) {
-        if (bytes && std::fwrite(d, 1, bytes, f) != bytes) throw Failure(err_arg("short write to " + path));
+        if (bytes && std::fwrite(d, 1, bytes, f) != bytes) throw Failure(err_io("short write to " + path));
         static const char zero[8] = {0};
-        if (bytes % 8 && std::fwrite(zero, 1, 8 - bytes % 8, f) != 8 - bytes % 8) throw Failure(err_arg("short write to " + path));
+        if (bytes % 8 && std::fwrite(zero, 1, 8 - bytes % 8, f) != 8 - bytes % 8) throw Failure(err_io("short write to " + path));
     }
     void get(void* d, size_t bytes) {
-        if (bytes && std::fread(d, 1, bytes, f) != bytes) throw Failure(err_arg(path + " is truncated"));
+        if (bytes && std::fread(d, 1, bytes, f) != bytes) throw Failure(err_io(path + " is truncated"));
         char pad[8];
-        if (bytes % 8 && std::fread(pad, 1, 8 - bytes % 8, f) != 8 - bytes % 8) throw Failure(err_arg(path + " is truncated"));
+        if (bytes % 8 && std::fread(pad, 1, 8 - bytes % 8, f) != 8 - bytes % 8) throw Failure(err_io(path + " is truncated"));
+    }
+    void close() {                                  // buffered data reaches the file (or the failure is reported) here
+        FILE* g = f; f = nullptr;
+        if (g && std::fclose(g) != 0) throw Failure(err_io("cannot finish writing " + path));
     }
 };
 }  // namespace
@@ -359,7 +382,7 @@ vdb_status vdb_index_save(const vdb_index* x, const char* path) {
             const uint64_t cnt[2] = {n_lists, n_edges};
             out.put(cnt, 16); out.put(owners.data(), n_lists * 4); out.put(off.data(), (n_lists + 1) * 8); out.put(nb.data(), n_edges * 4);
         }
-        if (std::fflush(out.f) != 0) throw Failure(err_arg("short write to " + out.path));
+        out.close();
     });
 }
 vdb_status vdb_index_load(vdb_index* x, const char* path) {
@@ -372,21 +395,23 @@ vdb_status vdb_index_load(vdb_index* x, const char* path) {
         if (h.metric != (uint32_t)x->metric || h.dim != x->dim)
             throw Failure(err_arg(in.path + " holds metric " + std::to_string(h.metric) + ", dimension " + std::to_string(h.dim) + "; the index was created with metric " +
                                   std::to_string((int)x->metric) + ", dimension " + std::to_string(x->dim)));
-        if (h.n > 0xFFFFFFF0ull || h.n_layers > 64) throw Failure(err_arg(in.path + " has an implausible header"));
+        // nothing is allocated from a count the file cannot back with bytes
+        std::fseek(in.f, 0, SEEK_END); const uint64_t file_bytes = (uint64_t)std::ftell(in.f); std::fseek(in.f, (long)sizeof h, SEEK_SET);
+        if (h.n > 0x7FFFFFF0ull || h.n_layers > 64 || h.n * (13 + 4 * h.dim) > file_bytes) throw Failure(err_arg(in.path + " has an implausible header"));
         std::vector<uint64_t> ids(h.n); std::vector<uint32_t> levels(h.n); std::vector<uint8_t> del(h.n); std::vector<float> vecs(h.n * h.dim);
         in.get(ids.data(), h.n * 8); in.get(levels.data(), h.n * 4); in.get(del.data(), h.n); in.get(vecs.data(), h.n * h.dim * 4);
         std::vector<std::vector<uint32_t>> owners(h.n_layers), nbs(h.n_layers); std::vector<std::vector<uint64_t>> offs(h.n_layers);
         std::vector<vdb_layer_csr> csr(h.n_layers);
         for (size_t l = 0; l < h.n_layers; ++l) {
             uint64_t cnt[2]; in.get(cnt, 16);
-            if (cnt[0] > h.n || cnt[1] > (uint64_t)1 << 40) throw Failure(err_arg(in.path + ": layer " + std::to_string(l) + " has implausible sizes"));
+            if (cnt[0] > h.n || cnt[1] > file_bytes / 4) throw Failure(err_arg(in.path + ": layer " + std::to_string(l) + " has implausible sizes"));
             owners[l].resize(cnt[0]); offs[l].resize(cnt[0] + 1); nbs[l].resize(cnt[1]);
             in.get(owners[l].data(), cnt[0] * 4); in.get(offs[l].data(), (cnt[0] + 1) * 8); in.get(nbs[l].data(), cnt[1] * 4);
             if (offs[l].back() != cnt[1]) throw Failure(err_arg(in.path + ": layer " + std::to_string(l) + " offsets do not cover its neighbours"));
-            csr[l] = {(size_t)cnt[0], owners[l].data(), offs[l].data(), nbs[l].data()};
+            csr[l] = {(size_t)cnt[0], owners[l].data(), offs[l].data(), nbs[l].data(), (size_t)cnt[1]};
         }
         x->import_graph(h.n, ids.data(), levels.data(), vecs.data(), del.data(), h.n_layers, csr.data(), h.has_entry != 0, h.entry_id, h.current_max_level);
-        x->level_draws = h.level_draws; x->sample_draws = h.sample_draws;
+        x->level_draws = h.level_draws; x->sample_draws = h.sample_draws; x->opts.seed = h.seed;     // the saved build's random streams continue
     });
 }
 vdb_status vdb_index_device_info(const vdb_index* x, size_t* n_slots, size_t* row_stride_floats, size_t* l0_edges, size_t* upper_edges, size_t* bytes_total) {
@@ -429,7 +454,7 @@ vdb_status vdb_segment_search_with_filter(const vdb_segment* s, const float* q, 
     return guard([&] { need(s, "segment"); need(q, "query"); emit(s->search_with_filter(q, len, top_k, f), out, out_n); });
 }
 vdb_status vdb_segment_search_unfiltered(const vdb_segment* s, const float* q, size_t len, size_t top_k, vdb_scored_point* out, size_t* out_n) {
-    need(s, "segment");
+    if (!s) { set_last_error("segment is NULL"); return VDB_ERR_ARGUMENT; }
     return vdb_index_search(s->hnsw.get(), q, len, top_k, out, out_n);
 }
 vdb_status vdb_segment_post_filter(const vdb_segment* s, const float* q, size_t len, size_t top_k, const vdb_filter* f, vdb_scored_point* out, size_t* out_n) {

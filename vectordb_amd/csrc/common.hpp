@@ -26,6 +26,7 @@ inline Error err_search(const std::string& s) { return {VDB_ERR_SEARCH, "Search 
 inline Error err_not_found(uint64_t id) { return {VDB_ERR_NOT_FOUND, "Point with ID " + std::to_string(id) + " not found"}; }   // errors.rs:10
 inline Error err_panic(const std::string& s) { return {VDB_ERR_PANIC, s}; }
 inline Error err_arg(const std::string& s) { return {VDB_ERR_ARGUMENT, s}; }
+inline Error err_io(const std::string& s) { return {VDB_ERR_IO, "I/O error: " + s}; }                                    // errors.rs:19
 inline Error err_device(const std::string& s) { return {VDB_ERR_DEVICE, s}; }
 
 struct Failure : std::exception {

@@ -107,7 +107,9 @@ uint32_t vdb_index::append_rows(const uint64_t* pids, const float* v, size_t n) 
     for (size_t i = 0; i < n; ++i) std::memcpy(&hvecs[(first + i) * dim], &padded[i * stride], dim * sizeof(float));
     for (size_t i = 0; i < n; ++i) {
         const uint32_t s = first + (uint32_t)i;
-        ids.push_back(pids[i]); slot_of[pids[i]] = s; deleted.push_back(0); live.insert(pids[i]);
+        ids.push_back(pids[i]); slot_of[pids[i]] = s;
+        if (pending_deleted.erase(pids[i])) { deleted.push_back(1); ++n_deleted; }       // marked deleted before it existed (hnsw.rs:112)
+        else { deleted.push_back(0); live.insert(pids[i]); }
         const size_t level = draw_level();
         levels.push_back((uint32_t)level);
         for (size_t l = 0; l <= level; ++l) list_or_default(l, s).push_back(s);
@@ -996,6 +998,7 @@ void vdb_index::insert_batch(const uint64_t* pids, const float* v, size_t n, siz
 
 void vdb_index::mark_deleted(uint64_t id) {                                          // hnsw.rs:111-117
     auto it = slot_of.find(id);
+    if (it == slot_of.end()) pending_deleted.insert(id);
     if (it != slot_of.end() && !deleted[it->second]) { deleted[it->second] = 1; ++n_deleted; live.erase(id); deleted_dirty = true; }
     if (entry_point && *entry_point == id) {
         if (live.empty()) entry_point = std::nullopt; else entry_point = *live.begin();
@@ -1009,26 +1012,46 @@ void vdb_index::add_bidirectional_edge(size_t level, uint32_t a, uint32_t b) {  
 
 void vdb_index::import_graph(size_t n, const uint64_t* pids, const uint32_t* lv, const float* vecs, const uint8_t* del,
                              size_t n_layers, const vdb_layer_csr* csr, bool has_entry, uint64_t entry, size_t cur_max) {
-    use_device();
-    ids.clear(); slot_of.clear(); levels.clear(); hvecs.clear(); layers.clear(); deleted.clear(); live.clear();
-    dirty0.clear(); dirty0_mark.clear(); need_full = true;
-    n_deleted = 0; rows_on_device = 0;
-    ids.assign(pids, pids + n); hvecs.assign(vecs, vecs + n * dim);
-    levels.resize(n); deleted.assign(n, 0);
-    for (size_t i = 0; i < n; ++i) {
-        slot_of[pids[i]] = (uint32_t)i; levels[i] = lv ? lv[i] : 0;
-        if (del && del[i]) { deleted[i] = 1; ++n_deleted; } else live.insert(pids[i]);
-    }
+    // ---- validate everything and build the new host state aside: a bad graph leaves the index as it was ----
+    if (n >= 0x7FFFFFFFull) throw Failure(err_arg("more than 2^31 points in one index"));
+    std::unordered_map<uint64_t, uint32_t> nslot; nslot.reserve(n * 2);
+    for (size_t i = 0; i < n; ++i)
+        if (!nslot.emplace(pids[i], (uint32_t)i).second) throw Failure(err_arg("id " + std::to_string(pids[i]) + " occurs twice"));
+    if (has_entry && !nslot.count(entry)) throw Failure(err_arg("entry id unknown"));
+    std::vector<HostLayer> nlayers(n_layers);
     for (size_t l = 0; l < n_layers; ++l) {
-        if (layers.size() <= l) layers.resize(l + 1);
-        for (size_t k = 0; k < csr[l].n_lists; ++k) {
-            if (csr[l].owners[k] >= n) throw Failure(err_arg("list owner out of range"));
-            auto& lst = list_or_default(l, csr[l].owners[k]);
-            lst.assign(csr[l].neighbors + csr[l].offsets[k], csr[l].neighbors + csr[l].offsets[k + 1]);
-            for (uint32_t x : lst) if (x >= n) throw Failure(err_arg("neighbour slot out of range"));
+        const vdb_layer_csr& c = csr[l];
+        const std::string where = "layer " + std::to_string(l);
+        if (c.n_lists && (!c.owners || !c.offsets)) throw Failure(err_arg(where + ": owners / offsets are NULL"));
+        if (c.n_edges && !c.neighbors) throw Failure(err_arg(where + ": neighbors is NULL"));
+        if (c.n_lists == 0) { if (c.n_edges) throw Failure(err_arg(where + ": neighbours without lists")); continue; }
+        if (c.offsets[0] != 0 || c.offsets[c.n_lists] != c.n_edges) throw Failure(err_arg(where + ": offsets do not cover its neighbours"));
+        for (size_t k = 0; k < c.n_lists; ++k)
+            if (c.offsets[k] > c.offsets[k + 1] || c.offsets[k + 1] > c.n_edges) throw Failure(err_arg(where + ": offsets of list " + std::to_string(k) + " are not ascending"));
+        for (size_t e = 0; e < c.n_edges; ++e) if (c.neighbors[e] >= n) throw Failure(err_arg(where + ": neighbour slot out of range"));
+        HostLayer& L = nlayers[l];
+        L.idx.assign(n, -1); L.lists.resize(c.n_lists); L.owner.resize(c.n_lists);
+        for (size_t k = 0; k < c.n_lists; ++k) {
+            const uint32_t o = c.owners[k];
+            if (o >= n) throw Failure(err_arg(where + ": list owner out of range"));
+            if (L.idx[o] >= 0) throw Failure(err_arg(where + ": slot " + std::to_string(o) + " owns two lists"));
+            L.idx[o] = (int32_t)k; L.owner[k] = o;
+            L.lists[k].assign(c.neighbors + c.offsets[k], c.neighbors + c.offsets[k + 1]);
         }
     }
-    if (has_entry) { if (!slot_of.count(entry)) throw Failure(err_arg("entry id unknown")); entry_point = entry; } else entry_point = std::nullopt;
+    // ---- take over ----
+    use_device();
+    ids.assign(pids, pids + n); slot_of.swap(nslot); hvecs.assign(vecs, vecs + n * dim); layers.swap(nlayers);
+    levels.resize(n); deleted.assign(n, 0); live.clear(); pending_deleted.clear();
+    dirty0.clear(); dirty0_mark.clear(); need_full = true;
+    dirty_upper.clear(); dirty_upper_lost = false; upper_dirty = true;
+    delta_slot.clear(); delta_pos.clear(); delta_val.clear();
+    n_deleted = 0; rows_on_device = 0;
+    for (size_t i = 0; i < n; ++i) {
+        levels[i] = lv ? lv[i] : 0;
+        if (del && del[i]) { deleted[i] = 1; ++n_deleted; } else live.insert(pids[i]);
+    }
+    if (has_entry) entry_point = entry; else entry_point = std::nullopt;
     current_max_level = cur_max;
     // rows go to the device as given (already in stored form)
     d_vecs.reserve(std::max<size_t>(n, 1) * stride, stream, false); d_ids.reserve(std::max<size_t>(n, 1), stream, false);

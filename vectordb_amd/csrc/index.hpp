@@ -60,6 +60,7 @@ struct vdb_index {
     std::vector<uint32_t> levels; std::vector<float> hvecs;     // n x dim, stored form
     std::vector<vdb::HostLayer> layers;
     std::vector<uint8_t> deleted; size_t n_deleted = 0; std::set<uint64_t> live;
+    std::set<uint64_t> pending_deleted;      // ids marked deleted before they were inserted (hnsw.rs:112 takes any id)
     std::optional<uint64_t> entry_point; size_t current_max_level = 0;
     uint64_t level_draws = 0, sample_draws = 0;
     // device state
