@@ -165,6 +165,7 @@ _SIGS = {
     "index_search_batch_dev": (_I, [_VP, _VP, _SZ, _SZ, _SZ, _VP, _VP, _VP, _VP]),
     "index_exact_knn_batch": (_I, [_VP, _VP, _SZ, _SZ, _SZ, _VP, _VP]),
     "index_exact_knn_batch_dev": (_I, [_VP, _VP, _SZ, _SZ, _VP, _VP, _VP]),
+    "index_exact_knn_batch_dev_noalloc": (_I, [_VP, _VP, _SZ, _SZ, _VP, _VP, _VP]),
     "index_mark_deleted": (_I, [_VP, _U64]), "index_contains": (_I, [_VP, _U64]), "index_len": (_SZ, [_VP]),
     "index_metric": (_I, [_VP]), "index_m": (_SZ, [_VP]), "index_ef": (_SZ, [_VP]),
     "index_max_level_cap": (_SZ, [_VP]), "index_dim": (_SZ, [_VP]), "index_current_max_level": (_SZ, [_VP]),

@@ -226,6 +226,12 @@ vdb_status vdb_index_exact_knn_batch_dev(const vdb_index* x, const float* d_q, s
         const_cast<vdb_index*>(x)->exact_knn(d_q, nq, top_k, true, d_out, d_out_n, (hipStream_t)stream);
     });
 }
+vdb_status vdb_index_exact_knn_batch_dev_noalloc(const vdb_index* x, const float* d_q, size_t nq, size_t top_k, vdb_scored_point* d_out, uint32_t* d_out_n, void* stream) {
+    return guard([&] {
+        need(x, "index"); need(d_q, "d_queries"); need(d_out, "d_out"); need(d_out_n, "d_out_n");
+        const_cast<vdb_index*>(x)->exact_knn_static(d_q, nq, top_k, d_out, d_out_n, (hipStream_t)stream);
+    });
+}
 vdb_status vdb_index_mark_deleted(vdb_index* x, uint64_t id) { return guard([&] { need(x, "index"); x->mark_deleted(id); }); }
 int vdb_index_contains(const vdb_index* x, uint64_t id) { return x->slot_of.count(id) != 0; }
 size_t vdb_index_len(const vdb_index* x) { return x->len(); }

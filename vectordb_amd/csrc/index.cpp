@@ -698,6 +698,20 @@ void vdb_index::exact_knn(const float* q, size_t nq, size_t top_k, bool dev, vdb
     VDB_HIP(hipStreamSynchronize(s));
 }
 
+void vdb_index::exact_knn_static(const float* d_q, size_t nq, size_t top_k, vdb_scored_point* d_out, uint32_t* d_out_n, hipStream_t s) {
+    if (nq == 0) return;
+    std::lock_guard<std::mutex> lk(mu);
+    use_device();
+    if (!s) s = stream;
+    // bringing the device copy up to date may allocate: this entry point refuses instead
+    if (deleted_dirty || rows_on_device != ids.size())
+        throw Failure(err_arg("exact k-NN without allocation: the index has edits that are not on the device yet; call vdb_index_sync_device first"));
+    const GraphView g = view();
+    if (opts.arith != VDB_ARITH_FAST || !knn_mfma_supported(g, (uint32_t)top_k))
+        throw Failure(err_arg("exact k-NN without allocation needs a FAST index that holds rows and top_k in 1..28"));
+    launch_exact_knn_mfma_static(g, d_q, (uint32_t)nq, (uint32_t)top_k, d_out, d_out_n, s);
+}
+
 void vdb_index::exact_knn_rows(const float* q, size_t nq, size_t top_k, const std::vector<uint32_t>& rows, vdb_scored_point* out, uint32_t* out_n) {
     if (nq == 0) return;
     if (rows.empty() || top_k == 0) { std::memset(out_n, 0, nq * sizeof(uint32_t)); return; }

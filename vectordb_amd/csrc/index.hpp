@@ -127,6 +127,8 @@ struct vdb_index {
     void search_batch_dev(const float* d_q, size_t nq, size_t top_k, size_t ef_search, vdb_scored_point* d_out, uint32_t* d_out_n,
                           vdb_query_stats* d_stats, hipStream_t s);
     void exact_knn(const float* q, size_t nq, size_t top_k, bool dev, vdb_scored_point* out, uint32_t* out_n, hipStream_t s);
+    // exact k-NN on device buffers without any allocation (static scratch of the library; FAST index, top_k <= 28, no pending edits)
+    void exact_knn_static(const float* d_q, size_t nq, size_t top_k, vdb_scored_point* d_out, uint32_t* d_out_n, hipStream_t s);
     // exact k-NN restricted to `rows` (live slots): the rows are gathered into a dense table first
     void exact_knn_rows(const float* q, size_t nq, size_t top_k, const std::vector<uint32_t>& rows, vdb_scored_point* out, uint32_t* out_n);
     std::vector<float> score_rows(uint32_t query_slot, const std::vector<uint32_t>& slots);

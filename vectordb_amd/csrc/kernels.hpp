@@ -111,6 +111,11 @@ bool knn_mfma_supported(const GraphView& g, uint32_t top_k);
 size_t knn_mfma_scratch_words(uint32_t n, uint32_t nq);
 void launch_exact_knn_mfma(const GraphView& g, const float* queries, uint32_t nq, uint32_t top_k, vdb_scored_point* out, uint32_t* out_n,
                            uint32_t* scratch, hipStream_t s);
+// The same pass on a static scratch area inside the library's code object (no allocation; 16 MiB per GPU, shared by every
+// call on that GPU): throws when 2 * rows + queries * candidates-per-chunk words do not fit.
+void launch_exact_knn_mfma_static(const GraphView& g, const float* queries, uint32_t nq, uint32_t top_k, vdb_scored_point* out, uint32_t* out_n,
+                                  hipStream_t s);
+size_t knn_mfma_static_words();
 void launch_topk_merge(const vdb_scored_point* lists, const uint32_t* counts, uint32_t n_shards, uint32_t nq, uint32_t k,
                        vdb_scored_point* out, uint32_t* out_n, hipStream_t s);
 

@@ -7,6 +7,7 @@
 // one chunk fall within the fp32 rounding error of the contraction (~1e-6 relative) of it.
 #include "device_common.hpp"
 #include <algorithm>
+#include <mutex>
 
 namespace vdb {
 namespace {
@@ -422,9 +423,9 @@ __global__ void __launch_bounds__(64) knn_rerank_kernel(GraphView gv, const floa
 
 // Blocks of one launch do equal work, so the launch lasts ceil(blocks / resident blocks) rounds: the base set is cut
 // into the number of chunks that wastes least of the last round (more chunks also mean more candidates to re-rank).
-inline uint32_t pick_chunks(uint32_t n, uint32_t nq, uint32_t resident) {
+inline uint32_t pick_chunks(uint32_t n, uint32_t nq, uint32_t resident, uint32_t max_chunks) {
     const uint32_t qblocks = (nq + MQ - 1) / MQ;
-    const uint32_t cmax = std::max<uint32_t>(1, std::min<uint32_t>(64, n / 4096));
+    const uint32_t cmax = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(64, max_chunks), n / 4096));
     uint32_t best = 1; double best_cost = 1e30;
     for (uint32_t c = 1; c <= cmax; ++c) {
         const uint32_t rounds = (c * qblocks + resident - 1) / resident;
@@ -442,20 +443,20 @@ uint32_t resident_blocks(Kernel kernel, size_t lds) {
     return (uint32_t)std::max(1, cus) * (uint32_t)std::max(1, per_cu);
 }
 template <int KH, int KP>
-uint32_t launch_mfma(const GraphView& g, const float* queries, uint32_t nq, const float* scale, const float* bias, uint32_t* slots, hipStream_t st) {
+uint32_t launch_mfma(const GraphView& g, const float* queries, uint32_t nq, const float* scale, const float* bias, uint32_t* slots, uint32_t max_chunks, hipStream_t st) {
     constexpr int K = 2 * KH;
     const size_t lds = (size_t)MT * (K + 4) * 4 + 2 * MT * 4 + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8;
-    const uint32_t n_chunks = pick_chunks(g.n, nq, resident_blocks(knn_mfma_kernel<KH, KP>, lds));
+    const uint32_t n_chunks = pick_chunks(g.n, nq, resident_blocks(knn_mfma_kernel<KH, KP>, lds), max_chunks);
     hipLaunchKernelGGL((knn_mfma_kernel<KH, KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, queries, nq, scale, bias, slots, n_chunks);
     return n_chunks;
 }
 template <int KP>
-uint32_t launch_mfma_any(const GraphView& g, const float* queries, uint32_t nq, const float* scale, const float* bias, uint32_t* slots, hipStream_t st) {
-    if (g.stride <= 64) return launch_mfma<32, KP>(g, queries, nq, scale, bias, slots, st);
-    if (g.stride <= 128) return launch_mfma<64, KP>(g, queries, nq, scale, bias, slots, st);
-    if (g.stride <= 256) return launch_mfma<128, KP>(g, queries, nq, scale, bias, slots, st);
+uint32_t launch_mfma_any(const GraphView& g, const float* queries, uint32_t nq, const float* scale, const float* bias, uint32_t* slots, uint32_t max_chunks, hipStream_t st) {
+    if (g.stride <= 64) return launch_mfma<32, KP>(g, queries, nq, scale, bias, slots, max_chunks, st);
+    if (g.stride <= 128) return launch_mfma<64, KP>(g, queries, nq, scale, bias, slots, max_chunks, st);
+    if (g.stride <= 256) return launch_mfma<128, KP>(g, queries, nq, scale, bias, slots, max_chunks, st);
     const size_t lds = (size_t)2 * LT * LDK * 4 + 2 * LT * 4 + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8;
-    const uint32_t n_chunks = pick_chunks(g.n, nq, resident_blocks(knn_mfma_long_kernel<KP>, lds));
+    const uint32_t n_chunks = pick_chunks(g.n, nq, resident_blocks(knn_mfma_long_kernel<KP>, lds), max_chunks);
     hipLaunchKernelGGL((knn_mfma_long_kernel<KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, queries, nq, scale, bias, slots, n_chunks);
     return n_chunks;
 }
@@ -467,20 +468,68 @@ bool knn_mfma_supported(const GraphView& g, uint32_t top_k) { return top_k >= 1 
 // room for the largest chunk count and candidate width the launch may pick
 size_t knn_mfma_scratch_words(uint32_t n, uint32_t nq) { return 2 * (size_t)n + (size_t)nq * std::max<uint32_t>(1, std::min<uint32_t>(64, n / 4096)) * 32; }
 
-// scratch: knn_mfma_scratch_words() dwords = [scale n][bias n][candidate slots]
-void launch_exact_knn_mfma(const GraphView& g, const float* queries, uint32_t nq, uint32_t top_k, vdb_scored_point* out, uint32_t* out_n,
-                           uint32_t* scratch, hipStream_t st) {
-    if (nq == 0) return;
+// scratch: [scale n][bias n][candidate slots: nq x chunks x KP], chunks <= max_chunks
+static void run_exact_knn_mfma(const GraphView& g, const float* queries, uint32_t nq, uint32_t top_k, vdb_scored_point* out, uint32_t* out_n,
+                               uint32_t* scratch, uint32_t max_chunks, hipStream_t st) {
     float* scale = reinterpret_cast<float*>(scratch); float* bias = scale + g.n;
     uint32_t* slots = scratch + 2 * (size_t)g.n;
     hipLaunchKernelGGL(knn_prepare_kernel, dim3((g.n + 31) / 32), dim3(256), 0, st, g, scale, bias);
     VDB_HIP(hipGetLastError());
     const uint32_t kp = knn_kp(top_k);
-    const uint32_t n_chunks = kp == 16 ? launch_mfma_any<16>(g, queries, nq, scale, bias, slots, st) : launch_mfma_any<32>(g, queries, nq, scale, bias, slots, st);
+    const uint32_t n_chunks = kp == 16 ? launch_mfma_any<16>(g, queries, nq, scale, bias, slots, max_chunks, st)
+                                       : launch_mfma_any<32>(g, queries, nq, scale, bias, slots, max_chunks, st);
     VDB_HIP(hipGetLastError());
     const size_t lds = (size_t)g.stride * 4 + (size_t)top_k * 16;
     hipLaunchKernelGGL(knn_rerank_kernel, dim3(nq), dim3(64), lds, st, g, queries, top_k, slots, n_chunks * kp, out, out_n);
     VDB_HIP(hipGetLastError());
+}
+
+// scratch: knn_mfma_scratch_words() dwords
+void launch_exact_knn_mfma(const GraphView& g, const float* queries, uint32_t nq, uint32_t top_k, vdb_scored_point* out, uint32_t* out_n,
+                           uint32_t* scratch, hipStream_t st) {
+    if (nq == 0) return;
+    run_exact_knn_mfma(g, queries, nq, top_k, out, out_n, scratch, 64, st);
+}
+
+// ---- the same pass on a scratch area that is part of the library's code object: nothing is allocated ----
+// One array per GPU (each device that loads the library holds its own copy until the process ends); every call on a
+// device shares it, so calls that overlap on one GPU race.  All of it is rewritten by the kernels before it is read
+// (scale / bias by knn_prepare_kernel, every candidate slot of every (query, chunk) by the contraction), so nothing
+// has to be cleared between calls.
+constexpr size_t KNN_STATIC_WORDS = size_t(4) << 20;                       // 16 MiB
+static __device__ __align__(256) uint32_t knn_static_scratch[KNN_STATIC_WORDS];
+
+size_t knn_mfma_static_words() { return KNN_STATIC_WORDS; }
+
+// Device address of this GPU's copy of knn_static_scratch (the array's name is a host-side stand-in, not an address
+// a kernel can use); looked up once per device with that device current.
+static uint32_t* knn_static_scratch_ptr() {
+    constexpr int MAX_DEV = 64;
+    static std::mutex mu;
+    static uint32_t* ptr[MAX_DEV] = {nullptr};
+    int dev = 0;
+    VDB_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEV) throw Failure(err_device("device ordinal beyond the static scratch table"));
+    std::lock_guard<std::mutex> lk(mu);
+    if (!ptr[dev]) {
+        void* p = nullptr;
+        VDB_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(knn_static_scratch)));
+        if (!p) throw Failure(err_device("hipGetSymbolAddress returned no address for the static scratch"));
+        ptr[dev] = static_cast<uint32_t*>(p);
+    }
+    return ptr[dev];
+}
+
+void launch_exact_knn_mfma_static(const GraphView& g, const float* queries, uint32_t nq, uint32_t top_k, vdb_scored_point* out, uint32_t* out_n,
+                                  hipStream_t st) {
+    if (nq == 0) return;
+    const uint32_t kp = knn_kp(top_k);
+    const size_t fixed = 2 * (size_t)g.n, per_chunk = (size_t)nq * kp;
+    if (fixed + per_chunk > KNN_STATIC_WORDS)
+        throw Failure(err_arg("exact k-NN without allocation: 2 * rows + queries * " + std::to_string(kp) + " = " + std::to_string(fixed + per_chunk) +
+                              " words exceed the static scratch of " + std::to_string(KNN_STATIC_WORDS) + " words (16 MiB); use vdb_index_exact_knn_batch_dev"));
+    const uint32_t max_chunks = (uint32_t)std::min<size_t>(64, (KNN_STATIC_WORDS - fixed) / per_chunk);
+    run_exact_knn_mfma(g, queries, nq, top_k, out, out_n, knn_static_scratch_ptr(), max_chunks, st);
 }
 
 }  // namespace vdb
