@@ -334,9 +334,23 @@ size_t vdb_segment_payload_count(const vdb_segment* s);                         
  * payload index (hnsw.rs:585-689); f may be NULL. */
 vdb_status vdb_segment_in_place_filtered_search(const vdb_segment* s, const float* q, size_t len, size_t top_k,
                                                 const vdb_filter* f, vdb_scored_point* out, size_t* out_n);
+/* The same on device buffers (extension): queries, results and counts are device-resident, the work is
+ * enqueued on `stream` (NULL = the index's own stream) and the call returns without waiting for it.  With a
+ * filter the segment must be in VDB_FILTER_MASKED mode (the literal walk of hnsw.rs:585-689 picks its entry and
+ * reports filter errors on the host). */
+vdb_status vdb_segment_search_batch_dev(const vdb_segment* s, const float* d_queries, size_t nq, size_t top_k,
+                                        size_t ef_search, const vdb_filter* f, vdb_scored_point* d_out, uint32_t* d_out_n, void* stream);
 /* Compile a filter to its device bitmaps (pass / error bits per slot) and return the number of
- * passing live points (extension; searches do this on demand and cache the result). */
+ * passing live points (extension; searches do this on demand and cache the result).  The tree of
+ * filters.rs:23-75 is evaluated on the GPU over the segment's payload columns: Match on a scalar scatters the
+ * posting list of the inverted index (stores.rs:55-61) when it is short and scans the key's column otherwise,
+ * Compare (payload.rs:36-114) scans the column, And / Or / Not combine bitmaps word by word with the
+ * reference's short-circuit and Err propagation. */
 vdb_status vdb_segment_compile_filter(const vdb_segment* s, const vdb_filter* f, size_t* n_pass, size_t* n_err);
+/* Host copies of the compiled bitmaps, (len + 31) / 32 words each: bit i of word w belongs to the
+ * (32 w + i)-th inserted point still held by the index (insertion order; after a purge: ascending id).
+ * pass = evaluate_filter is Ok(true), err = it is Err; bits of tombstoned points are unspecified. */
+vdb_status vdb_segment_filter_bitmaps(const vdb_segment* s, const vdb_filter* f, uint32_t* pass, uint32_t* err, size_t cap_words);
 
 /* ---------------------------------------------------------------- scale-out --------------- */
 

@@ -196,6 +196,8 @@ _SIGS = {
     "segment_payload_index": (_VP, [_VP]), "segment_payload_count": (_SZ, [_VP]),
     "segment_in_place_filtered_search": (_I, [_VP, _VP, _SZ, _SZ, _VP, _VP, _PSZ]),
     "segment_compile_filter": (_I, [_VP, _VP, _PSZ, _PSZ]),
+    "segment_filter_bitmaps": (_I, [_VP, _VP, _VP, _VP, _SZ]),
+    "segment_search_batch_dev": (_I, [_VP, _VP, _SZ, _SZ, _SZ, _VP, _VP, _VP, _VP]),
     "topk_merge_dev": (_I, [_VP, _VP, _SZ, _SZ, _SZ, _VP, _VP, _VP]),
     "score_scan_dev": (_I, [_VP, _SZ, _VP, _SZ, _SZ, _SZ, _I, _I, _VP, _VP]),
     "default_options": (None, [_VP]),
@@ -561,6 +563,13 @@ def bind(cdll, prefix="vdb_", required=None):
             a, b = C.c_size_t(0), C.c_size_t(0)
             check(fn.segment_compile_filter(self._h, filter._h, C.byref(a), C.byref(b)))
             return a.value, b.value
+        def filter_bitmaps(self, filter):
+            """-> (pass, err) as bool arrays over the slots (insertion order)."""
+            n = self.hnsw().len(); words = (n + 31) // 32
+            p = np.zeros(max(words, 1), np.uint32); e = np.zeros(max(words, 1), np.uint32)
+            check(fn.segment_filter_bitmaps(self._h, filter._h, _ptr(p), _ptr(e), len(p)))
+            unpack = lambda w: np.unpackbits(w.view(np.uint8), bitorder="little")[:n].astype(bool)
+            return unpack(p), unpack(e)
         def set_filter_mode(self, mode): fn.segment_set_filter_mode(self._h, int(mode))
 
     return SimpleNamespace(

@@ -483,6 +483,22 @@ vdb_status vdb_segment_in_place_filtered_search(const vdb_segment* s, const floa
 vdb_status vdb_segment_compile_filter(const vdb_segment* s, const vdb_filter* f, size_t* n_pass, size_t* n_err) {
     return guard([&] { need(s, "segment"); need(f, "filter"); const auto b = s->compile(*f); if (n_pass) *n_pass = b->n_pass; if (n_err) *n_err = b->n_err; });
 }
+vdb_status vdb_segment_filter_bitmaps(const vdb_segment* s, const vdb_filter* f, uint32_t* pass, uint32_t* err, size_t cap_words) {
+    return guard([&] {
+        need(s, "segment"); need(f, "filter"); need(pass, "pass"); need(err, "err");
+        if (cap_words < (s->hnsw->len() + 31) / 32) throw Failure(err_arg("capacity too small"));
+        s->filter_bitmaps(*f, pass, err);
+    });
+}
+vdb_status vdb_segment_search_batch_dev(const vdb_segment* s, const float* d_q, size_t nq, size_t top_k, size_t ef_search, const vdb_filter* f,
+                                        vdb_scored_point* d_out, uint32_t* d_out_n, void* stream) {
+    return guard([&] {
+        need(s, "segment");
+        if (nq == 0) return;
+        need(d_q, "d_queries"); need(d_out, "d_out"); need(d_out_n, "d_out_n");
+        s->search_batch_dev(d_q, nq, top_k, ef_search, f, d_out, d_out_n, (hipStream_t)stream);
+    });
+}
 
 // ---- scale-out ----
 vdb_status vdb_topk_merge_dev(const vdb_scored_point* d_lists, const uint32_t* d_counts, size_t n_shards, size_t nq, size_t k,

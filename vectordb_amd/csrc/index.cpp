@@ -648,7 +648,7 @@ void vdb_index::search_batch(const float* q, size_t nq, size_t top_k, size_t ef_
 }
 
 void vdb_index::search_batch_dev(const float* d_q, size_t nq, size_t top_k, size_t ef_search, vdb_scored_point* d_out, uint32_t* d_out_n,
-                                 vdb_query_stats* d_stats, hipStream_t s) {
+                                 vdb_query_stats* d_stats, hipStream_t s, const FilterArgs* fa) {
     if (nq == 0) return;
     std::lock_guard<std::mutex> lk(mu);
     use_device();
@@ -658,10 +658,11 @@ void vdb_index::search_batch_dev(const float* d_q, size_t nq, size_t top_k, size
     if (!entry_point) { VDB_HIP(hipMemsetAsync(d_out_n, 0, nq * sizeof(uint32_t), s)); return; }
     sync_device();
     SearchArgs a{};
-    a.g = view(); a.mode = MODE_SEARCH; a.arith = opts.arith; a.queries = d_q; a.nq = (uint32_t)nq;
+    a.g = view(); a.mode = fa ? fa->mode : MODE_SEARCH; a.arith = opts.arith; a.queries = d_q; a.nq = (uint32_t)nq;
     a.entry = slot_of.at(*entry_point); a.max_level = (uint32_t)current_max_level;
     auto fl = first_live_slot(); a.fallback_live = fl ? *fl : NONE32;
     a.ef = (uint32_t)ef_; a.top_k = (uint32_t)top_k; a.out = d_out; a.out_n = d_out_n; a.stats = d_stats;
+    if (fa && fa->bits) { a.pass_bits = fa->bits->d_pass.p; a.err_bits = fa->bits->d_err.p; }
     if (!a.stats) {                       // the kernels report per-query flags: one private array per stream
         auto& buf = s_stats_by_stream[s];
         buf.reserve(nq, s, false);
@@ -673,21 +674,28 @@ void vdb_index::search_batch_dev(const float* d_q, size_t nq, size_t top_k, size
     run_search(a, nq, s, false, d_q);
 }
 
-void vdb_index::exact_knn(const float* q, size_t nq, size_t top_k, bool dev, vdb_scored_point* out, uint32_t* out_n, hipStream_t s) {
+void vdb_index::exact_knn(const float* q, size_t nq, size_t top_k, bool dev, vdb_scored_point* out, uint32_t* out_n, hipStream_t s,
+                          const uint32_t* rowmap, size_t n_rows) {
     if (nq == 0) return;
     std::lock_guard<std::mutex> lk(mu);
     use_device();
     if (!s) s = stream;
     sync_device();
-    const GraphView g = view();
+    GraphView g = view();
+    if (rowmap) { g.rowmap = rowmap; g.n = (uint32_t)n_rows; }
+    if (g.n == 0 || top_k == 0) {
+        if (dev) VDB_HIP(hipMemsetAsync(out_n, 0, nq * sizeof(uint32_t), s)); else std::memset(out_n, 0, nq * sizeof(uint32_t));
+        return;
+    }
     // FAST: MFMA candidate pass + strict re-rank; STRICT (and shapes the MFMA kernel does not take): every pair in strict arithmetic
     const bool mfma = opts.arith == VDB_ARITH_FAST && knn_mfma_supported(g, (uint32_t)top_k) && !std::getenv("VDB_KNN_STRICT");
-    const uint32_t chunks = exact_knn_chunks((uint32_t)ids.size());
-    if (mfma) s_knn_words.reserve(knn_mfma_scratch_words(g.n, (uint32_t)nq), s, false);
-    else s_knn.reserve(nq * chunks * top_k, s, false);
+    const uint32_t chunks = exact_knn_chunks(g.n);
+    DevBuf<uint32_t>& words = s_knn_words_by_stream[s]; DevBuf<vdb_scored_point>& lists = s_knn_by_stream[s];
+    if (mfma) words.reserve(knn_mfma_scratch_words(g.n, (uint32_t)nq), s, false);
+    else lists.reserve(nq * chunks * top_k, s, false);
     auto run = [&](const float* dq, vdb_scored_point* dout, uint32_t* dn) {
-        if (mfma) launch_exact_knn_mfma(g, dq, (uint32_t)nq, (uint32_t)top_k, dout, dn, s_knn_words.p, s);
-        else launch_exact_knn(g, dq, (uint32_t)nq, (uint32_t)top_k, dout, dn, s_knn.p, chunks, s);
+        if (mfma) launch_exact_knn_mfma(g, dq, (uint32_t)nq, (uint32_t)top_k, dout, dn, words.p, s);
+        else launch_exact_knn(g, dq, (uint32_t)nq, (uint32_t)top_k, dout, dn, lists.p, chunks, s);
     };
     if (dev) { run(q, out, out_n); return; }
     s_q.reserve(nq * dim, s, false); s_out.reserve(nq * top_k, s, false); s_n.reserve(nq, s, false);
@@ -710,32 +718,6 @@ void vdb_index::exact_knn_static(const float* d_q, size_t nq, size_t top_k, vdb_
     if (opts.arith != VDB_ARITH_FAST || !knn_mfma_supported(g, (uint32_t)top_k))
         throw Failure(err_arg("exact k-NN without allocation needs a FAST index that holds rows and top_k in 1..28"));
     launch_exact_knn_mfma_static(g, d_q, (uint32_t)nq, (uint32_t)top_k, d_out, d_out_n, s);
-}
-
-void vdb_index::exact_knn_rows(const float* q, size_t nq, size_t top_k, const std::vector<uint32_t>& rows, vdb_scored_point* out, uint32_t* out_n) {
-    if (nq == 0) return;
-    if (rows.empty() || top_k == 0) { std::memset(out_n, 0, nq * sizeof(uint32_t)); return; }
-    std::lock_guard<std::mutex> lk(mu);
-    use_device();
-    hipStream_t s = stream;
-    sync_device();
-    const uint32_t p = (uint32_t)rows.size();
-    s_slots.reserve(p, s, false); s_sub_vecs.reserve((size_t)p * stride, s, false); s_sub_ids.reserve(p, s, false);
-    VDB_HIP(hipMemcpyAsync(s_slots.p, rows.data(), (size_t)p * 4, hipMemcpyHostToDevice, s));
-    GraphView g = view();
-    launch_gather_rows(g, s_slots.p, p, s_sub_vecs.p, s_sub_ids.p, s);
-    g.vecs = s_sub_vecs.p; g.ids = s_sub_ids.p; g.n = p; g.deleted = nullptr;
-    const bool mfma = opts.arith == VDB_ARITH_FAST && knn_mfma_supported(g, (uint32_t)top_k) && !std::getenv("VDB_KNN_STRICT");
-    const uint32_t chunks = exact_knn_chunks(p);
-    if (mfma) s_knn_words.reserve(knn_mfma_scratch_words(p, (uint32_t)nq), s, false);
-    else s_knn.reserve(nq * chunks * top_k, s, false);
-    s_q.reserve(nq * dim, s, false); s_out.reserve(nq * top_k, s, false); s_n.reserve(nq, s, false);
-    VDB_HIP(hipMemcpyAsync(s_q.p, q, nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
-    if (mfma) launch_exact_knn_mfma(g, s_q.p, (uint32_t)nq, (uint32_t)top_k, s_out.p, s_n.p, s_knn_words.p, s);
-    else launch_exact_knn(g, s_q.p, (uint32_t)nq, (uint32_t)top_k, s_out.p, s_n.p, s_knn.p, chunks, s);
-    VDB_HIP(hipMemcpyAsync(out, s_out.p, nq * top_k * sizeof(vdb_scored_point), hipMemcpyDeviceToHost, s));
-    VDB_HIP(hipMemcpyAsync(out_n, s_n.p, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    VDB_HIP(hipStreamSynchronize(s));
 }
 
 std::vector<float> vdb_index::score_rows(uint32_t query_slot, const std::vector<uint32_t>& slots) {

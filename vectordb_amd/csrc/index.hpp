@@ -41,12 +41,23 @@ struct HostLayer {                       // layers[l]: HashMap<PointId, Vec<Poin
     std::vector<uint32_t> owner;
 };
 
-struct FilterBits {                      // a Filter compiled against the segment's payloads
-    std::vector<uint32_t> pass, err;     // per slot; missing payload / Err -> pass = 0
-    DevBuf<uint32_t> d_pass, d_err;
-    size_t n_pass = 0, n_err = 0; uint64_t version = 0;
-    std::vector<uint32_t> live_pass;     // passing slots that are not tombstoned, ascending
+// A Filter compiled against the segment's payloads: device bitmaps over the slots.
+struct FilterBits {
+    DevBuf<uint32_t> d_pass, d_err;      // filter true / evaluate_filter returned Err; a slot without payload has neither bit
+    DevBuf<uint32_t> d_rows;             // live passing slots, ascending (built when the narrow-filter scan will use it)
+    bool have_rows = false;
+    size_t n_slots = 0, n_pass = 0, n_err = 0;   // counts over live (not tombstoned) slots
+    uint64_t version = 0;
     uint64_t last_used = 0;              // cache clock of the segment (least recently used entries are dropped)
+};
+
+// One payload key as columns over the slots (host mirror + device copy, appended to as points arrive).
+struct PayloadColumn {
+    std::vector<uint8_t> kind;           // 0 = the slot's payload lacks the key (or the slot has no payload), else 1 + vdb_value_kind
+    std::vector<int64_t> bits;           // Int value / f64 bit pattern / Bool as 0, 1 / dictionary code of a Str / 0 for lists
+    std::vector<uint32_t> list_slots;    // slots whose value is a list: the leaves that can be true for a list are finished on the host
+    std::map<std::string, uint32_t> str_code; std::vector<std::string> strs;   // dictionary of the key's Str values
+    DevBuf<uint8_t> d_kind; DevBuf<int64_t> d_bits; size_t on_device = 0;
 };
 
 }  // namespace vdb
@@ -89,9 +100,12 @@ struct vdb_index {
     mutable std::mutex mu;
     mutable void* h_pin = nullptr; mutable size_t h_pin_bytes = 0;     // pinned staging of small search batches (one query per call is the reference's shape)
     void* pinned(size_t bytes) const;
-    mutable vdb::DevBuf<float> s_q, s_raw, s_sub_vecs; mutable vdb::DevBuf<uint64_t> s_sub_ids; mutable vdb::DevBuf<vdb_scored_point> s_out, s_knn, s_cand;
-    mutable vdb::DevBuf<uint32_t> s_knn_words, s_n, s_slots, s_qslots, s_lvl, s_off, s_nb, s_nbc, s_bin, s_bout, s_hash, s_spill; mutable vdb::DevBuf<vdb_query_stats> s_stats;
+    mutable vdb::DevBuf<float> s_q, s_raw; mutable vdb::DevBuf<vdb_scored_point> s_out, s_cand;
+    mutable vdb::DevBuf<uint32_t> s_n, s_slots, s_qslots, s_lvl, s_off, s_nb, s_nbc, s_bin, s_bout, s_hash, s_spill; mutable vdb::DevBuf<vdb_query_stats> s_stats;
     mutable std::map<hipStream_t, vdb::DevBuf<vdb_query_stats>> s_stats_by_stream;
+    // exact k-NN scratch per stream: device-buffer calls return before their kernels have run, so calls on different
+    // streams must not share it
+    mutable std::map<hipStream_t, vdb::DevBuf<uint32_t>> s_knn_words_by_stream; mutable std::map<hipStream_t, vdb::DevBuf<vdb_scored_point>> s_knn_by_stream;
 
     vdb_index(vdb_metric metric, size_t m, size_t ef, size_t cap, size_t dim, const vdb_options& o);
     ~vdb_index();
@@ -125,12 +139,12 @@ struct vdb_index {
     void search_batch(const float* q, size_t nq, size_t top_k, size_t ef_search, const FilterArgs& fa,
                       vdb_scored_point* out, uint32_t* out_n, vdb_query_stats* stats);
     void search_batch_dev(const float* d_q, size_t nq, size_t top_k, size_t ef_search, vdb_scored_point* d_out, uint32_t* d_out_n,
-                          vdb_query_stats* d_stats, hipStream_t s);
-    void exact_knn(const float* q, size_t nq, size_t top_k, bool dev, vdb_scored_point* out, uint32_t* out_n, hipStream_t s);
+                          vdb_query_stats* d_stats, hipStream_t s, const FilterArgs* fa = nullptr);
+    // rowmap (device, n_rows live slots): exact k-NN over those slots only, read where they lie
+    void exact_knn(const float* q, size_t nq, size_t top_k, bool dev, vdb_scored_point* out, uint32_t* out_n, hipStream_t s,
+                   const uint32_t* rowmap = nullptr, size_t n_rows = 0);
     // exact k-NN on device buffers without any allocation (static scratch of the library; FAST index, top_k <= 28, no pending edits)
     void exact_knn_static(const float* d_q, size_t nq, size_t top_k, vdb_scored_point* d_out, uint32_t* d_out_n, hipStream_t s);
-    // exact k-NN restricted to `rows` (live slots): the rows are gathered into a dense table first
-    void exact_knn_rows(const float* q, size_t nq, size_t top_k, const std::vector<uint32_t>& rows, vdb_scored_point* out, uint32_t* out_n);
     std::vector<float> score_rows(uint32_t query_slot, const std::vector<uint32_t>& slots);
     std::vector<float> score_all_rows(uint32_t query_slot);
     std::vector<vdb_scored_point> search_from_row(uint32_t row_slot, uint32_t entry_slot, size_t ef_search);
@@ -165,6 +179,12 @@ struct vdb_segment {
     mutable std::map<std::string, std::shared_ptr<vdb::FilterBits>> filter_cache;
     mutable uint64_t filter_clock = 0;
 
+    // payload columns and the bitmap of slots that own a payload: what the device-side filter compiler reads
+    mutable std::map<std::string, vdb::PayloadColumn> columns;
+    mutable std::vector<uint32_t> has_bits; mutable vdb::DevBuf<uint32_t> d_has; mutable bool has_dirty = true; mutable size_t has_words_on_device = 0;
+    void note_payload(uint32_t slot, const vdb_payload& p);
+    void rebuild_columns();
+
     explicit vdb_segment(vdb_index* h) : hnsw(h) {}
     uint64_t insert(const float* v, size_t len, const vdb_payload* p);
     void insert_batch(const float* v, size_t n, size_t len, const vdb_payload* const* p, uint64_t* out_ids);
@@ -178,7 +198,12 @@ struct vdb_segment {
     std::vector<vdb_scored_point> in_place_filtered_search(const float* q, size_t len, size_t top_k, const vdb_filter* f) const;
     void search_batch(const float* q, size_t nq, size_t len, size_t top_k, size_t ef_search, const vdb_filter* f,
                       vdb_scored_point* out, uint32_t* out_n) const;
+    // the same on device buffers, enqueued on `s` without a host synchronisation (masked filter mode when f is given)
+    void search_batch_dev(const float* d_q, size_t nq, size_t top_k, size_t ef_search, const vdb_filter* f,
+                          vdb_scored_point* d_out, uint32_t* d_out_n, hipStream_t s) const;
     std::shared_ptr<const vdb::FilterBits> compile(const vdb_filter& f) const;
+    // host copies of a compiled filter's bitmaps ((len + 31) / 32 words each): what the tests compare with evaluate_filter
+    void filter_bitmaps(const vdb_filter& f, uint32_t* pass, uint32_t* err) const;
     void build_filter_aware_edges(uint64_t id, const vdb_payload& p, const std::vector<std::string>& keys);
     void filter_aware_edges_batch(const std::vector<uint64_t>& pids, const vdb_payload* const* p);
 

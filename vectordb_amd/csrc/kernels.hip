@@ -287,9 +287,10 @@ __global__ void __launch_bounds__(64) exact_knn_kernel(GraphView gv, const float
     const uint32_t per = (gv.n + n_chunks - 1) / n_chunks;
     const uint32_t r_begin = blockIdx.x * per, r_end = min(gv.n, r_begin + per);
     for (uint32_t rb = r_begin; rb < r_end; rb += WAVE) {
-        const uint32_t r = rb + lane;
-        const bool live = r < r_end && !(gv.deleted && bit_test(gv.deleted, r));
-        const float* row = gv.vecs + (size_t)(r < r_end ? r : r_begin) * stride;
+        const uint32_t rpos = rb + lane < r_end ? rb + lane : r_begin;
+        const uint32_t r = gv.rowmap ? gv.rowmap[rpos] : rpos;                      // the slot behind this position
+        const bool live = rb + lane < r_end && !(gv.deleted && bit_test(gv.deleted, r));
+        const float* row = gv.vecs + (size_t)r * stride;
         float acc[KNN_QT], accb = -0.0f;
 #pragma unroll
         for (int t = 0; t < KNN_QT; ++t) acc[t] = -0.0f;
@@ -406,26 +407,6 @@ void launch_patch_words(uint32_t* dst, const uint32_t* idx, const uint32_t* val,
 void launch_patch_blocks(uint32_t* adj0, const uint32_t* idx, const uint32_t* blocks, uint32_t n, hipStream_t st) {
     if (n == 0) return;
     hipLaunchKernelGGL(patch_blocks_kernel, dim3(n), dim3(64), 0, st, adj0, idx, blocks);
-    VDB_HIP(hipGetLastError());
-}
-
-namespace {
-// one wave per gathered row, 16 bytes per lane and trip
-__global__ void __launch_bounds__(256) gather_rows_kernel(GraphView g, const uint32_t* __restrict__ slots, uint32_t n,
-                                                          float* __restrict__ out_vecs, uint64_t* __restrict__ out_ids) {
-    const uint32_t row = blockIdx.x * 4 + threadIdx.x / WAVE;
-    if (row >= n) return;
-    const int lane = lane_id();
-    const uint32_t s = slots[row];
-    const float4* src = reinterpret_cast<const float4*>(g.vecs + (size_t)s * g.stride);
-    float4* dst = reinterpret_cast<float4*>(out_vecs + (size_t)row * g.stride);
-    for (uint32_t c = lane; c < g.stride / 4; c += WAVE) dst[c] = src[c];
-    if (lane == 0) out_ids[row] = g.ids[s];
-}
-}  // namespace
-void launch_gather_rows(const GraphView& g, const uint32_t* slots, uint32_t n, float* out_vecs, uint64_t* out_ids, hipStream_t st) {
-    if (n == 0) return;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, st, g, slots, n, out_vecs, out_ids);
     VDB_HIP(hipGetLastError());
 }
 

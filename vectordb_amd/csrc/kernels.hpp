@@ -33,6 +33,9 @@ struct GraphView {
     const uint32_t* ublk; const uint32_t* ublk_ref;
     const uint32_t* deleted;    // bitmap (1 = tombstone) or nullptr when nothing is deleted
     int metric;
+    // Exact k-NN over a subset (filtered search): position p of the scan stands for slot rowmap[p] and n counts
+    // positions; nullptr = every slot in order.  The rows are read where they lie, nothing is copied.
+    const uint32_t* rowmap;
 };
 
 enum SearchMode : int { MODE_SEARCH = 0, MODE_BUILD = 1, MODE_MASKED = 2, MODE_LITERAL = 3 };
@@ -101,8 +104,6 @@ void launch_exact_knn(const GraphView& g, const float* queries, uint32_t nq, uin
 void launch_patch_blocks(uint32_t* adj0, const uint32_t* idx, const uint32_t* blocks, uint32_t n, hipStream_t s);
 // dst[idx[i]] = val[i] for i < n (distinct idx).
 void launch_patch_words(uint32_t* dst, const uint32_t* idx, const uint32_t* val, uint32_t n, hipStream_t st);
-// out_vecs row j <- row slots[j] of the table (stride floats), out_ids[j] <- its PointId.
-void launch_gather_rows(const GraphView& g, const uint32_t* slots, uint32_t n, float* out_vecs, uint64_t* out_ids, hipStream_t s);
 // adj0 block slot[i]: neighbour word 1 + pos[i] <- val[i], degree word <- max(degree, pos[i] + 1): appends to layer-0 lists.
 void launch_patch_entries(uint32_t* adj0, const uint32_t* slot, const uint32_t* pos, const uint32_t* val, uint32_t n, hipStream_t s);
 uint32_t exact_knn_chunks(uint32_t n);
@@ -116,6 +117,32 @@ void launch_exact_knn_mfma(const GraphView& g, const float* queries, uint32_t nq
 void launch_exact_knn_mfma_static(const GraphView& g, const float* queries, uint32_t nq, uint32_t top_k, vdb_scored_point* out, uint32_t* out_n,
                                   hipStream_t s);
 size_t knn_mfma_static_words();
+// ---- payload filters on the device (filter_kernels.hip) ----
+enum : int { FILTER_LEAF_MATCH = 0, FILTER_LEAF_COMPARE = 1 };
+enum : int { FILTER_AND = 0, FILTER_OR = 1, FILTER_NOT = 2, FILTER_TRUE = 3, FILTER_FALSE = 4 };
+struct FilterLeafArgs {
+    const uint8_t* kind;        // per slot of the key's column: 0 = the payload lacks the key, else 1 + vdb_value_kind
+    const int64_t* bits;        // per slot: Int value, f64 bit pattern, Bool as 0 / 1, dictionary code of a Str
+    uint32_t n_col;             // slots the column covers (further slots lack the key)
+    uint32_t n, words;          // slots of the segment, bitmap words
+    int leaf, op, want_kind;    // FILTER_LEAF_*, vdb_cmp_op, kind of the filter's value
+    int64_t want_bits;          // the filter's value in the encoding of `bits`
+    const uint8_t* table;       // Str values: outcome per dictionary code (computed once per leaf on the host)
+    uint32_t table_n;
+    const uint32_t* has;        // bitmap of the slots that own a payload
+    uint32_t* pass; uint32_t* err;
+};
+void launch_filter_leaf(const FilterLeafArgs& a, hipStream_t s);
+void launch_filter_scatter(const uint32_t* slots, uint32_t m, uint32_t* pass, hipStream_t s);
+void launch_filter_patch(const uint32_t* slots, const uint8_t* tri, uint32_t m, uint32_t* pass, uint32_t* err, hipStream_t s);
+// acc (ap, ae) <- acc OP b; `has` = slots that own a payload (Not and the constants are confined to them)
+void launch_filter_combine(int op, uint32_t* ap, uint32_t* ae, const uint32_t* bp, const uint32_t* be, const uint32_t* has, uint32_t words, hipStream_t s);
+// clears bits beyond n and adds the live (not tombstoned) pass / err counts to counts[0] / counts[1] (zero them first)
+void launch_filter_count(uint32_t* pass, uint32_t* err, const uint32_t* deleted, uint32_t n, uint32_t* counts, hipStream_t s);
+// rows <- ascending slots with pass & ~deleted; block_sums holds filter_compact_blocks(n) words of scratch
+uint32_t filter_compact_blocks(uint32_t n);
+void launch_filter_compact(const uint32_t* pass, const uint32_t* deleted, uint32_t n, uint32_t* block_sums, uint32_t* rows, hipStream_t s);
+
 void launch_topk_merge(const vdb_scored_point* lists, const uint32_t* counts, uint32_t n_shards, uint32_t nq, uint32_t k,
                        vdb_scored_point* out, uint32_t* out_n, hipStream_t s);
 

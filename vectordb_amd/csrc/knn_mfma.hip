@@ -32,7 +32,7 @@ __device__ __forceinline__ void knn_compact(const GraphView& gv, uint32_t* cnt, 
     const uint32_t n = __builtin_amdgcn_readfirstlane(cnt[qi]);
     uint2 e = make_uint2(0x7f800000u, 0xFFFFFFFFu);
     uint64_t id = ~0ull;
-    if ((uint32_t)lane < n) { e = buf[qi * CAP + lane]; id = gv.ids[e.y]; }
+    if ((uint32_t)lane < n) { e = buf[qi * CAP + lane]; id = gv.ids[gv.rowmap ? gv.rowmap[e.y] : e.y]; }
     const float k = __uint_as_float(e.x);
     const uint32_t id_lo = (uint32_t)id, id_hi = (uint32_t)(id >> 32);
     uint32_t rank = 0;
@@ -60,7 +60,8 @@ __global__ void __launch_bounds__(256) knn_prepare_kernel(GraphView gv, float* _
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t r = t >> 3, part = t & 7;                   // eight lanes share a row, 16 bytes each per step
     const bool in = r < gv.n;
-    const float4* row = reinterpret_cast<const float4*>(gv.vecs + (size_t)(in ? r : 0) * gv.stride);
+    const uint32_t slot = in ? (gv.rowmap ? gv.rowmap[r] : r) : 0u;
+    const float4* row = reinterpret_cast<const float4*>(gv.vecs + (size_t)slot * gv.stride);
     float s = 0.f;
     for (uint32_t c = part; c < (gv.stride >> 2); c += 8) {
         const float4 v = row[c];
@@ -72,7 +73,7 @@ __global__ void __launch_bounds__(256) knn_prepare_kernel(GraphView gv, float* _
     if (gv.metric == VDB_EUCLIDEAN) { sc = -2.f; bi = s; }
     else if (gv.metric == VDB_DOT) sc = -1.f;
     else sc = s > 0.f ? -1.0f / __builtin_sqrtf(s) : 0.f;
-    if (gv.deleted && bit_test(gv.deleted, r)) { sc = 0.f; bi = INF_F; }
+    if (gv.deleted && bit_test(gv.deleted, slot)) { sc = 0.f; bi = INF_F; }
     scale[r] = sc; bias[r] = bi;
 }
 
@@ -117,7 +118,8 @@ __global__ void __launch_bounds__(256) knn_mfma_kernel(GraphView gv, const float
     auto fetch = [&](uint32_t tile_base) {
         const uint32_t r = tile_base + lrow;
         const bool in = r < r_end;
-        const float* row = gv.vecs + (size_t)(in ? r : r_begin) * stride;
+        const uint32_t rp = in ? r : r_begin;
+        const float* row = gv.vecs + (size_t)(gv.rowmap ? gv.rowmap[rp] : rp) * stride;
 #pragma unroll
         for (int v = 0; v < VPT; ++v) {
             const uint32_t c = lpart * (K / 8) + v * 4;
@@ -175,7 +177,7 @@ __global__ void __launch_bounds__(256) knn_mfma_kernel(GraphView gv, const float
 #pragma unroll
                     for (int v = hv * 8; v < hv * 8 + 8; ++v) {
                         const uint32_t row = tb + (v / 4) * 8 + h * 4 + (v % 4);
-                        if (key[v] < thr || (key[v] == thr && thr_id != 0 && gv.ids[row] < thr_id)) {
+                        if (key[v] < thr || (key[v] == thr && thr_id != 0 && gv.ids[gv.rowmap ? gv.rowmap[row] : row] < thr_id)) {
                             const uint32_t pos = atomicAdd(&cnt[ql], 1u);
                             buf[ql * KNN_CAP + pos] = make_uint2(__float_as_uint(key[v]), row);
                         }
@@ -245,7 +247,8 @@ __global__ void __launch_bounds__(256) knn_mfma_long_kernel(GraphView gv, const 
         auto fetch_a = [&](uint32_t kc) {
             const uint32_t r = tb + lrow;
             const bool in = r < r_end;
-            const float* row = gv.vecs + (size_t)(in ? r : r_begin) * stride;
+            const uint32_t rp = in ? r : r_begin;
+            const float* row = gv.vecs + (size_t)(gv.rowmap ? gv.rowmap[rp] : rp) * stride;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const uint32_t c = kc * KC + lhalf * 16 + v * 4;
@@ -321,7 +324,7 @@ __global__ void __launch_bounds__(256) knn_mfma_long_kernel(GraphView gv, const 
 #pragma unroll
                         for (int v = hv * 8; v < hv * 8 + 8; ++v) {
                             const uint32_t row = tb + t * 32 + (v / 4) * 8 + h * 4 + (v % 4);
-                            if (key[v] < thr || (key[v] == thr && thr_id != 0 && gv.ids[row] < thr_id)) {
+                            if (key[v] < thr || (key[v] == thr && thr_id != 0 && gv.ids[gv.rowmap ? gv.rowmap[row] : row] < thr_id)) {
                                 const uint32_t pos = atomicAdd(&cnt[ql], 1u);
                                 buf[ql * KNN_CAP + pos] = make_uint2(__float_as_uint(key[v]), row);
                             }
@@ -403,8 +406,9 @@ __global__ void __launch_bounds__(64) knn_rerank_kernel(GraphView gv, const floa
     TopKList L{lkey, lid, lraw, 0, top_k};
     for (uint32_t b = 0; b < per_query; b += WAVE) {
         const uint32_t i = b + lane;
-        const uint32_t s = i < per_query ? slots[(size_t)q * per_query + i] : NONE32;
+        uint32_t s = i < per_query ? slots[(size_t)q * per_query + i] : NONE32;      // a position of the scan
         const bool valid = s != NONE32;
+        if (valid && gv.rowmap) s = gv.rowmap[s];
         float raw = 0.f; uint64_t idv = 0;
         if (valid) { raw = strict_pair(ql, gv.vecs + (size_t)s * stride, dim, gv.metric, true); idv = gv.ids[s]; }
         const float k = gv.metric == VDB_DOT ? -raw : raw;

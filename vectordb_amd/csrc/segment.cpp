@@ -2,6 +2,7 @@
 // bookkeeping, tombstones and purge on the host; every distance on the GPU.
 #include <algorithm>
 #include <cstring>
+#include <functional>
 
 #include "index.hpp"
 
@@ -114,6 +115,7 @@ uint64_t vdb_segment::insert(const float* v, size_t len, const vdb_payload* p) {
     if (p) {
         payload_index.insert(pid, *p);
         payloads[pid] = *p;
+        note_payload(hnsw->slot_of.at(pid), *p);
         ++payload_version;
         const std::vector<std::string> keys = p->scalar_keys();
         if (!keys.empty()) filter_aware_edges(*hnsw, payload_index, payloads, pid, *p, keys);
@@ -133,6 +135,7 @@ void vdb_segment::insert_batch(const float* v, size_t n, size_t len, const vdb_p
         if (p && p[i]) {
             payload_index.insert(pids[i], *p[i]);
             payloads[pids[i]] = *p[i];
+            note_payload(hnsw->slot_of.at(pids[i]), *p[i]);
         }
     }
     ++payload_version;
@@ -301,6 +304,7 @@ void vdb_segment::purge() {                                                     
     }
     hnsw = std::move(nh); payload_index = std::move(npi); payloads = std::move(npl);
     deleted.clear();
+    rebuild_columns();
     { std::lock_guard<std::mutex> lk(filter_mu); filter_cache.clear(); }
     ++payload_version;
 }
@@ -332,37 +336,208 @@ std::optional<uint64_t> vdb_segment::find_entry_point_matching_filter(const vdb_
     }
 }
 
-// Predicate -> per-slot bitmaps: pass (filter true) and err (evaluate_filter returned Err).  A slot
-// without a payload has neither bit (hnsw.rs:669 map_or(false), :391 continue).
+// Masked mode: when at most this fraction of the rows passes, the passing rows are scanned exactly
+// instead of walking the graph (a beam of fixed width meets too few passing rows to fill top_k).
+static bool masked_scan_pays(size_t n_pass, size_t n) {
+    const char* e = std::getenv("VDB_MASKED_SCAN");               // 0: never, 1: always
+    if (e) return std::atoi(e) != 0;
+    return n_pass <= 4096 || n_pass * 8 <= n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Payload columns: what the device-side filter compiler reads
+// ------------------------------------------------------------------------------------------------
+void vdb_segment::note_payload(uint32_t slot, const vdb_payload& p) {
+    if (has_bits.size() <= slot / 32) has_bits.resize(slot / 32 + 1, 0);
+    has_bits[slot / 32] |= 1u << (slot & 31); has_dirty = true;
+    for (const auto& f : p.fields) {
+        PayloadColumn& c = columns[f.first];
+        if (c.kind.size() <= slot) { c.kind.resize(slot + 1, 0); c.bits.resize(slot + 1, 0); }
+        c.kind[slot] = (uint8_t)(1 + f.second.kind());
+        int64_t b = 0;
+        switch (f.second.kind()) {
+            case VDB_T_INT: b = std::get<int64_t>(f.second.d); break;
+            case VDB_T_FLOAT: { const double d = std::get<OF64>(f.second.d).v; std::memcpy(&b, &d, 8); break; }
+            case VDB_T_BOOL: b = std::get<Bool8>(f.second.d).v != 0; break;
+            case VDB_T_STR: {
+                const std::string& str = std::get<std::string>(f.second.d);
+                auto it = c.str_code.find(str);
+                if (it == c.str_code.end()) { it = c.str_code.emplace(str, (uint32_t)c.strs.size()).first; c.strs.push_back(str); }
+                b = it->second; break;
+            }
+            default: c.list_slots.push_back(slot);
+        }
+        c.bits[slot] = b;
+        if (slot < c.on_device) c.on_device = slot;              // (a slot is written once; kept for safety)
+    }
+}
+
+void vdb_segment::rebuild_columns() {                              // after a purge: every point has a new slot
+    columns.clear(); has_bits.clear(); has_dirty = true;
+    for (const auto& kv : payloads) {
+        auto it = hnsw->slot_of.find(kv.first);
+        if (it != hnsw->slot_of.end()) note_payload(it->second, kv.second);
+    }
+    for (auto& c : columns) std::sort(c.second.list_slots.begin(), c.second.list_slots.end());
+}
+
+namespace {
+struct NodeBits { DevBuf<uint32_t> p, e; };
+}
+
+// Filter -> device bitmaps over the slots: pass (the filter is true) and err (evaluate_filter returned Err); a slot
+// without a payload has neither bit (hnsw.rs:669 map_or(false), :391 continue).  Match on a scalar goes through the
+// inverted index when its posting list is short (stores.rs:55-61: the list is scattered into the bitmap) and through the
+// key's column otherwise; Compare scans the column; And / Or / Not combine bitmaps word-wise.
 std::shared_ptr<const FilterBits> vdb_segment::compile(const vdb_filter& f) const {
     std::string key; f.serialise(key);
     const size_t n = hnsw->len();
     // one compilation at a time: two threads that ask for the same new filter get the same object
     std::lock_guard<std::mutex> lk(filter_mu);
     auto it = filter_cache.find(key);
-    if (it != filter_cache.end() && it->second->version == payload_version && it->second->pass.size() == (n + 31) / 32) {
+    if (it != filter_cache.end() && it->second->version == payload_version && it->second->n_slots == n) {
         it->second->last_used = ++filter_clock;
         return it->second;
     }
     auto fresh = std::make_shared<FilterBits>();
     FilterBits& fb = *fresh;
-    fb.pass.assign((n + 31) / 32, 0); fb.err.assign((n + 31) / 32, 0); fb.n_pass = fb.n_err = 0; fb.live_pass.clear();
-    for (size_t s = 0; s < n; ++s) {
-        auto pit = payloads.find(hnsw->ids[s]);
-        if (pit == payloads.end()) continue;
-        const Tri t = f.eval(pit->second);
-        if (t.s == Tri::True) { fb.pass[s >> 5] |= 1u << (s & 31); if (!hnsw->deleted[s]) { ++fb.n_pass; fb.live_pass.push_back((uint32_t)s); } }
-        else if (t.s == Tri::Err) { fb.err[s >> 5] |= 1u << (s & 31); if (!hnsw->deleted[s]) ++fb.n_err; }
-    }
+    fb.n_slots = n;
+    const uint32_t words = (uint32_t)((n + 31) / 32), w1 = std::max<uint32_t>(words, 1);
     {
-        std::lock_guard<std::mutex> dl(hnsw->mu);              // the index's stream is shared with its searches
-        hnsw->use_device();
-        const size_t w = std::max<size_t>(fb.pass.size(), 1);
-        fb.d_pass.reserve(w, hnsw->stream, false); fb.d_err.reserve(w, hnsw->stream, false);
-        if (!fb.pass.empty()) {
-            VDB_HIP(hipMemcpyAsync(fb.d_pass.p, fb.pass.data(), fb.pass.size() * 4, hipMemcpyHostToDevice, hnsw->stream));
-            VDB_HIP(hipMemcpyAsync(fb.d_err.p, fb.err.data(), fb.err.size() * 4, hipMemcpyHostToDevice, hnsw->stream));
-            VDB_HIP(hipStreamSynchronize(hnsw->stream));
+        vdb_index& h = *hnsw;
+        std::lock_guard<std::mutex> dl(h.mu);                     // the index's stream is shared with its searches
+        h.use_device();
+        h.sync_device();                                          // the tombstone bitmap the counts are taken against
+        hipStream_t st = h.stream;
+        // slots that own a payload
+        has_bits.resize(w1, 0);
+        if (has_dirty || has_words_on_device != w1) {
+            d_has.reserve(w1, st, false);
+            VDB_HIP(hipMemcpyAsync(d_has.p, has_bits.data(), (size_t)w1 * 4, hipMemcpyHostToDevice, st));
+            VDB_HIP(hipStreamSynchronize(st));
+            has_dirty = false; has_words_on_device = w1;
+        }
+        std::vector<std::unique_ptr<DevBuf<uint8_t>>> tables; std::vector<std::unique_ptr<DevBuf<uint32_t>>> lists;   // alive until the stream has run
+        std::vector<std::vector<uint8_t>> host_keep; std::vector<std::vector<uint32_t>> host_keep32;
+        auto column = [&](const std::string& k) -> PayloadColumn* {                   // device copy of a key's column, current up to slot n
+            auto ci = columns.find(k);
+            if (ci == columns.end()) return nullptr;
+            PayloadColumn& c = ci->second;
+            if (c.kind.size() < n) { c.kind.resize(n, 0); c.bits.resize(n, 0); }
+            c.d_kind.reserve(std::max<size_t>(n, 1), st, true); c.d_bits.reserve(std::max<size_t>(n, 1), st, true);
+            if (c.on_device < n) {
+                VDB_HIP(hipMemcpyAsync(c.d_kind.p + c.on_device, c.kind.data() + c.on_device, n - c.on_device, hipMemcpyHostToDevice, st));
+                VDB_HIP(hipMemcpyAsync(c.d_bits.p + c.on_device, c.bits.data() + c.on_device, (n - c.on_device) * 8, hipMemcpyHostToDevice, st));
+                VDB_HIP(hipStreamSynchronize(st));                 // the host vectors may grow before the copy has run otherwise
+                c.on_device = n;
+            }
+            return &c;
+        };
+        auto upload8 = [&](std::vector<uint8_t>&& v) -> const uint8_t* {
+            tables.emplace_back(new DevBuf<uint8_t>()); host_keep.emplace_back(std::move(v));
+            tables.back()->reserve(std::max<size_t>(host_keep.back().size(), 1), st, false);
+            if (!host_keep.back().empty()) VDB_HIP(hipMemcpyAsync(tables.back()->p, host_keep.back().data(), host_keep.back().size(), hipMemcpyHostToDevice, st));
+            return tables.back()->p;
+        };
+        auto upload32 = [&](std::vector<uint32_t>&& v) -> const uint32_t* {
+            lists.emplace_back(new DevBuf<uint32_t>()); host_keep32.emplace_back(std::move(v));
+            lists.back()->reserve(std::max<size_t>(host_keep32.back().size(), 1), st, false);
+            if (!host_keep32.back().empty()) VDB_HIP(hipMemcpyAsync(lists.back()->p, host_keep32.back().data(), host_keep32.back().size() * 4, hipMemcpyHostToDevice, st));
+            return lists.back()->p;
+        };
+        const char* force = std::getenv("VDB_FILTER_MATCH");      // tests: "postings" / "column" pin the path of Match leaves
+        std::function<void(const vdb_filter&, NodeBits&)> eval = [&](const vdb_filter& node, NodeBits& out) {
+            out.p.reserve(w1, st, false); out.e.reserve(w1, st, false);
+            switch (node.kind) {
+                case vdb_filter::Match: case vdb_filter::Compare: {
+                    const bool is_match = node.kind == vdb_filter::Match;
+                    // Match on a scalar with a short posting list: the inverted index names the passing points
+                    if (is_match && node.value.scalar()) {
+                        const std::set<uint64_t>* ids = payload_index.query_exact(node.key, node.value);
+                        const size_t len = ids ? ids->size() : 0;
+                        bool postings = len <= std::max<size_t>(4096, n / 64);
+                        if (force) postings = std::string(force) == "postings";
+                        if (postings) {
+                            VDB_HIP(hipMemsetAsync(out.p.p, 0, (size_t)w1 * 4, st)); VDB_HIP(hipMemsetAsync(out.e.p, 0, (size_t)w1 * 4, st));
+                            std::vector<uint32_t> slots; slots.reserve(len);
+                            if (ids) for (uint64_t id : *ids) { auto si = h.slot_of.find(id); if (si != h.slot_of.end() && (has_bits[si->second / 32] >> (si->second & 31) & 1u)) slots.push_back(si->second); }
+                            const uint32_t m = (uint32_t)slots.size();
+                            launch_filter_scatter(upload32(std::move(slots)), m, out.p.p, st);
+                            return;
+                        }
+                    }
+                    PayloadColumn* c = column(node.key);
+                    FilterLeafArgs a{};
+                    a.kind = c ? c->d_kind.p : nullptr; a.bits = c ? c->d_bits.p : nullptr; a.n_col = c ? (uint32_t)n : 0;
+                    a.n = (uint32_t)n; a.words = words; a.leaf = is_match ? FILTER_LEAF_MATCH : FILTER_LEAF_COMPARE; a.op = (int)node.op;
+                    a.want_kind = node.value.kind(); a.has = d_has.p; a.pass = out.p.p; a.err = out.e.p;
+                    switch (node.value.kind()) {
+                        case VDB_T_INT: a.want_bits = std::get<int64_t>(node.value.d); break;
+                        case VDB_T_FLOAT: { const double d = std::get<OF64>(node.value.d).v; std::memcpy(&a.want_bits, &d, 8); break; }
+                        case VDB_T_BOOL: a.want_bits = std::get<Bool8>(node.value.d).v != 0; break;
+                        case VDB_T_STR: {                           // one comparison per distinct string of the key
+                            const std::string& want = std::get<std::string>(node.value.d);
+                            std::vector<uint8_t> table(c ? c->strs.size() : 0);
+                            for (size_t i = 0; i < table.size(); ++i) table[i] = is_match ? c->strs[i] == want : cmp_apply(node.op, c->strs[i], want);
+                            a.table_n = (uint32_t)table.size(); a.table = upload8(std::move(table)); break;
+                        }
+                        default: break;
+                    }
+                    launch_filter_leaf(a, st);
+                    // list-valued fields: the few leaves that can hold for a list are evaluated on the host for those slots
+                    const bool list_leaf = is_match ? node.value.kind() >= VDB_T_LIST_INT
+                                                    : (node.value.kind() == VDB_T_LIST_STR || node.value.kind() == VDB_T_STR);
+                    if (c && list_leaf && !c->list_slots.empty()) {
+                        std::vector<uint32_t> slots; std::vector<uint8_t> tri;
+                        for (uint32_t s : c->list_slots) {
+                            if (s >= n) continue;
+                            auto pit = payloads.find(h.ids[s]);
+                            if (pit == payloads.end()) continue;
+                            const vdb_value* have = pit->second.get(node.key);
+                            if (!have || (!is_match && have->kind() != VDB_T_LIST_STR)) continue;
+                            const Tri t = node.eval(pit->second);
+                            slots.push_back(s); tri.push_back((uint8_t)t.s);
+                        }
+                        const uint32_t m = (uint32_t)slots.size();
+                        launch_filter_patch(upload32(std::move(slots)), upload8(std::move(tri)), m, out.p.p, out.e.p, st);
+                    }
+                    return;
+                }
+                case vdb_filter::And: case vdb_filter::Or: {
+                    const bool is_and = node.kind == vdb_filter::And;
+                    if (node.kids.empty()) { launch_filter_combine(is_and ? FILTER_TRUE : FILTER_FALSE, out.p.p, out.e.p, nullptr, nullptr, d_has.p, w1, st); return; }
+                    eval(node.kids[0], out);
+                    for (size_t k = 1; k < node.kids.size(); ++k) {
+                        NodeBits rhs; eval(node.kids[k], rhs);
+                        launch_filter_combine(is_and ? FILTER_AND : FILTER_OR, out.p.p, out.e.p, rhs.p.p, rhs.e.p, d_has.p, w1, st);
+                        VDB_HIP(hipStreamSynchronize(st));         // rhs is freed when it leaves scope
+                    }
+                    return;
+                }
+                default:
+                    eval(node.kids.at(0), out);
+                    launch_filter_combine(FILTER_NOT, out.p.p, out.e.p, nullptr, nullptr, d_has.p, w1, st);
+            }
+        };
+        NodeBits root;
+        if (words == 0) { root.p.reserve(1, st, false); root.e.reserve(1, st, false); VDB_HIP(hipMemsetAsync(root.p.p, 0, 4, st)); VDB_HIP(hipMemsetAsync(root.e.p, 0, 4, st)); }
+        else eval(f, root);
+        DevBuf<uint32_t> counts; counts.reserve(2, st, false);
+        VDB_HIP(hipMemsetAsync(counts.p, 0, 8, st));
+        const uint32_t* dele = h.n_deleted ? h.d_deleted.p : nullptr;
+        launch_filter_count(root.p.p, root.e.p, dele, (uint32_t)n, counts.p, st);
+        uint32_t hc[2] = {0, 0};
+        VDB_HIP(hipMemcpyAsync(hc, counts.p, 8, hipMemcpyDeviceToHost, st));
+        VDB_HIP(hipStreamSynchronize(st));
+        fb.n_pass = hc[0]; fb.n_err = hc[1];
+        std::swap(fb.d_pass.p, root.p.p); std::swap(fb.d_pass.cap, root.p.cap);
+        std::swap(fb.d_err.p, root.e.p); std::swap(fb.d_err.cap, root.e.cap);
+        if (masked_scan_pays(fb.n_pass, n) && fb.n_pass) {         // the narrow-filter scan reads the passing rows through this list
+            DevBuf<uint32_t> sums; sums.reserve(std::max<uint32_t>(filter_compact_blocks((uint32_t)n), 1), st, false);
+            fb.d_rows.reserve(fb.n_pass, st, false);
+            launch_filter_compact(fb.d_pass.p, dele, (uint32_t)n, sums.p, fb.d_rows.p, st);
+            VDB_HIP(hipStreamSynchronize(st));
+            fb.have_rows = true;
         }
     }
     fb.version = payload_version;
@@ -379,12 +554,15 @@ std::shared_ptr<const FilterBits> vdb_segment::compile(const vdb_filter& f) cons
     return fresh;
 }
 
-// Masked mode: when at most this fraction of the rows passes, the passing rows are scanned exactly
-// instead of walking the graph (a beam of fixed width meets too few passing rows to fill top_k).
-static bool masked_scan_pays(size_t n_pass, size_t n) {
-    const char* e = std::getenv("VDB_MASKED_SCAN");               // 0: never, 1: always
-    if (e) return std::atoi(e) != 0;
-    return n_pass <= 4096 || n_pass * 8 <= n;
+void vdb_segment::filter_bitmaps(const vdb_filter& f, uint32_t* pass, uint32_t* err) const {
+    const auto b = compile(f);
+    const size_t words = (b->n_slots + 31) / 32;
+    if (!words) return;
+    std::lock_guard<std::mutex> dl(hnsw->mu);
+    hnsw->use_device();
+    VDB_HIP(hipMemcpyAsync(pass, b->d_pass.p, words * 4, hipMemcpyDeviceToHost, hnsw->stream));
+    VDB_HIP(hipMemcpyAsync(err, b->d_err.p, words * 4, hipMemcpyDeviceToHost, hnsw->stream));
+    VDB_HIP(hipStreamSynchronize(hnsw->stream));
 }
 
 void vdb_segment::filtered_batch(const float* q, size_t nq, size_t len, size_t top_k, size_t useful_k, size_t ef_search, const vdb_filter* f,
@@ -395,12 +573,13 @@ void vdb_segment::filtered_batch(const float* q, size_t nq, size_t len, size_t t
     const std::shared_ptr<const FilterBits> bits = f ? compile(*f) : nullptr;     // alive until this call returns
     fa.bits = bits.get();
     if (h.opts.filter_mode == VDB_FILTER_MASKED) {
-        if (f && masked_scan_pays(bits->n_pass, h.len())) {
+        if (f && (bits->have_rows || bits->n_pass == 0) && masked_scan_pays(bits->n_pass, h.len())) {
             // the scan returns no tombstone, so the caller's over-fetch is not needed; rows of out stay top_k apart
             const size_t k = std::min(top_k, useful_k);
-            if (k == top_k) { h.exact_knn_rows(q, nq, k, bits->live_pass, out, out_n); return; }
+            if (bits->n_pass == 0) { std::memset(out_n, 0, nq * sizeof(uint32_t)); return; }
+            if (k == top_k) { h.exact_knn(q, nq, k, false, out, out_n, nullptr, bits->d_rows.p, bits->n_pass); return; }
             std::vector<vdb_scored_point> tmp(nq * k);
-            h.exact_knn_rows(q, nq, k, bits->live_pass, tmp.data(), out_n);
+            h.exact_knn(q, nq, k, false, tmp.data(), out_n, nullptr, bits->d_rows.p, bits->n_pass);
             for (size_t i = 0; i < nq; ++i) std::memcpy(out + i * top_k, tmp.data() + i * k, out_n[i] * sizeof(vdb_scored_point));
             return;
         }
@@ -495,4 +674,25 @@ void vdb_segment::search_batch(const float* q, size_t nq, size_t len, size_t top
         }
         out_n[i] = n;
     }
+}
+
+// Batched Segment::search / search_with_filter on device buffers.  The graph walk never returns a tombstone (hnsw.rs:475)
+// and the scan reads live rows only, so the over-fetch of segment.rs:110 / :134 changes nothing here and is left out.
+void vdb_segment::search_batch_dev(const float* d_q, size_t nq, size_t top_k, size_t ef_search, const vdb_filter* f,
+                                   vdb_scored_point* d_out, uint32_t* d_out_n, hipStream_t s) const {
+    if (live_count() == 0) throw Failure(err_search("No active points available to search."));
+    vdb_index& h = *hnsw;
+    if (!f) { h.search_batch_dev(d_q, nq, top_k, ef_search, d_out, d_out_n, nullptr, s); return; }
+    if (h.opts.filter_mode != VDB_FILTER_MASKED)
+        throw Failure(err_arg("filtered search on device buffers needs filter_mode = VDB_FILTER_MASKED (the literal walk picks its entry and reports errors on the host)"));
+    const std::shared_ptr<const FilterBits> bits = compile(*f);
+    if (bits->n_pass == 0) { h.use_device(); VDB_HIP(hipMemsetAsync(d_out_n, 0, nq * sizeof(uint32_t), s ? s : h.stream)); return; }
+    if (bits->have_rows && masked_scan_pays(bits->n_pass, h.len())) { h.exact_knn(d_q, nq, top_k, true, d_out, d_out_n, s, bits->d_rows.p, bits->n_pass); }
+    else {
+        vdb_index::FilterArgs fa; fa.mode = MODE_MASKED; fa.bits = bits.get();
+        h.search_batch_dev(d_q, nq, top_k, ef_search, d_out, d_out_n, nullptr, s, &fa);
+    }
+    // the bitmaps must outlive the launches: the cache holds them, and an evicted entry is kept until the stream has drained
+    h.use_device();
+    if (bits.use_count() == 1) VDB_HIP(hipStreamSynchronize(s ? s : h.stream));
 }
