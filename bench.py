@@ -11,6 +11,13 @@ picks the smallest beam that reaches recall@10 >= 0.95 and `value` is measured a
 N > 1 (launched by torch.distributed.run, one rank per GPU): every rank owns its own 1M-vector shard
 and sub-graph, searches the same query batch, and the per-shard top-k lists are merged after one
 RCCL all-gather; a unit is one query searched against one shard, so value = N * Q * K / time.
+
+Other configurations of the same path (the default line stays on the one above):
+  --config c3   GIST-shape: 1M x 960 fp32 cosine, 1000-query batch
+  --config c4   10M x 768 dot product with payload filters (1 %, 5 %, 10 %, 50 % of the rows pass), 10k-query
+                device-buffer batches through vdb_segment_search_batch_dev; one JSON line, `value` at the 10 % filter
+  --config c5   Deep100M-shape: 96-d L2, one 12.5M-row shard per rank (weak: 25M / 50M / 100M rows at 2 / 4 / 8 GPUs);
+                --c5-total 100000000 fixes the total instead (strong: every rank holds total / N rows)
 """
 import argparse
 import json
@@ -63,23 +70,39 @@ def recall_at_k(ann, ann_n, exact, k):
     return hits / (len(ann) * k)
 
 
+# name -> rows per rank, dimension, queries, metric (DistanceMetric value), Gaussian centres, generator seed, ef candidates
+CONFIGS = {
+    "c2": dict(n=1_000_000, dim=128, queries=10_000, metric=2, centres=4096, seed=0xC2, efs=[16, 32, 64, 96, 128, 144, 160, 176, 192, 224, 256],
+               metric_name="queries/sec at recall@10>=0.95 (1M x 128 L2)", shape="SIFT1M-shape"),
+    "c3": dict(n=1_000_000, dim=960, queries=1_000, metric=0, centres=1024, seed=0xC3, efs=[64, 128, 192, 256, 384, 512],
+               metric_name="queries/sec at recall@10>=0.95 (1M x 960 cosine)", shape="GIST-shape"),
+    "c5": dict(n=12_500_000, dim=96, queries=10_000, metric=2, centres=4096, seed=0xC5, efs=[32, 64, 128, 256],
+               metric_name="queries/sec (100M x 96 L2 over 8 shards), recall@10 reported", shape="Deep100M-shape"),
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=1_000_000)
-    ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--queries", type=int, default=10_000)
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--c5-total", type=int, default=0, help="c5: total rows over all ranks (strong scaling); 0 = 12.5M per rank")
+    ap.add_argument("--n", type=int, default=0, help="rows per rank (0 = the configuration's)")
+    ap.add_argument("--dim", type=int, default=0)
+    ap.add_argument("--queries", type=int, default=0)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--ef", type=int, default=0, help="0 = sweep and pick the smallest ef with recall >= target")
     ap.add_argument("--target-recall", type=float, default=0.95)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-queries", type=int, default=10_000)
+    ap.add_argument("--cpu-queries", type=int, default=0, help="queries of the CPU baseline sample (0 = all for c2, 1000 otherwise)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the timed steps rotate over (consecutive batches overlap, which hides the tail of "
                          "long-running queries at the end of each launch); 1 = strictly back to back")
     args = ap.parse_args()
+    if args.config == "c4":
+        return bench_c4(args)
+    cfg = CONFIGS[args.config]
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -94,18 +117,21 @@ def main():
     import vectordb_amd
     vdb = vectordb_amd.api()
 
-    N, D, Q, K = args.n, args.dim, args.queries, args.k
+    N, D, Q, K = args.n or cfg["n"], args.dim or cfg["dim"], args.queries or cfg["queries"], args.k
+    if args.config == "c5" and args.c5_total:
+        N = args.c5_total // world                               # strong scaling: the total is fixed, contiguous id ranges
+    METRIC, SEED = cfg["metric"], cfg["seed"]
     M, EF_BUILD = 16, 64
     t0 = time.time()
-    centres = np.random.default_rng(0xC2).uniform(0, 128, size=(4096, D)).astype(np.float32)
-    base = clustered(N, D, 0xC2 + 1 + rank, centres)
-    queries = clustered(Q, D, 0xC2 + 1000, centres)
+    centres = np.random.default_rng(SEED).uniform(0, 128, size=(cfg["centres"], D)).astype(np.float32)
+    base = clustered(N, D, SEED + 1 + rank, centres)
+    queries = clustered(Q, D, SEED + 1000, centres)
     ids = np.arange(N, dtype=np.uint64) + np.uint64(rank) * np.uint64(N)
     log(f"data: {N}x{D} base (shard {rank}/{world}), {Q} queries in {time.time()-t0:.1f}s")
 
     # ---- build the shard's graph on the GPU (hnsw.rs:119-208 linking rules, batched rounds) ----
     t0 = time.time()
-    index = vdb.HNSWIndex(vdb.DistanceMetric.Euclidean, M, EF_BUILD, 16, D, seed=0xC2 + rank, device=local_rank, arith=vdb.Arith.Fast)
+    index = vdb.HNSWIndex(vdb.DistanceMetric(METRIC), M, EF_BUILD, 16, D, seed=SEED + rank, device=local_rank, arith=vdb.Arith.Fast)
     step = 250_000
     for s in range(0, N, step):
         index.insert_batch(ids[s:s + step], base[s:s + step])
@@ -153,7 +179,7 @@ def main():
 
     # ---- ef sweep ----
     sweep = {}
-    efs = [args.ef] if args.ef else [16, 32, 64, 96, 128, 144, 160, 176, 192, 224, 256]
+    efs = [args.ef] if args.ef else cfg["efs"]
     chosen = None
     for ef in efs:
         search(ef); stream.synchronize()
@@ -236,13 +262,14 @@ def main():
 
     out, out_n, st = fetch()
     result = {
-        "metric": "queries/sec at recall@10>=0.95 (1M x 128 L2)", "value": value, "unit": "queries/s",
+        "metric": cfg["metric_name"], "value": value, "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"SIFT1M-shape synthetic: {N} x {D} fp32 L2 per GPU (clustered, 4096 Gaussian centres), "
+        "config": {"workload": f"{cfg['shape']} synthetic: {N} x {D} fp32 {('cosine', 'dot', 'L2')[METRIC]} per GPU (clustered, {cfg['centres']} Gaussian centres), "
                                f"{Q}-query batch, HNSW M={M} ef_construction={EF_BUILD}, top-{K}",
+                   "rccl_ranks": world if exchange else 0, "total_rows": N * world,
                    "ef_search": ef, "recall_at_10": sweep[ef]["recall"], "ef_sweep": sweep, "shards": world,
-                   "unit_note": "one unit = one query searched against one 1M-vector shard",
+                   "unit_note": f"one unit = one query searched against one {N}-vector shard",
                    "merged_queries_per_s": Q * args.steps / wall, "build_seconds": round(build_s, 1),
                    "exact_knn_seconds": round(exact_s, 3), "arith": "fast", "streams": n_streams,
                    "single_stream_ms_per_launch": kernel_ms},
@@ -254,11 +281,11 @@ def main():
         ora = pyoracle.load()
         t0 = time.time()
         g = index.export_graph()
-        ho = ora.HNSWIndex(ora.DistanceMetric.Euclidean, M, EF_BUILD, 16, D)
+        ho = ora.HNSWIndex(ora.DistanceMetric(METRIC), M, EF_BUILD, 16, D)
         ho.import_graph(g)
         log(f"oracle: graph handed over in {time.time()-t0:.1f}s")
         with_cpu = world == 1 and not args.no_cpu_baseline          # the CPU baseline is timed at N = 1 only
-        nqc = min(Q, args.cpu_queries) if with_cpu else Q
+        nqc = min(Q, args.cpu_queries or (Q if args.config == "c2" else 1000)) if with_cpu else Q
         ora.set_threads(1 if with_cpu else min(os.cpu_count() or 1, 16))
         t0 = time.perf_counter()
         ref, refn, rst = ho.search_batch(queries[:nqc], K, ef_search=ef, with_stats=True)
@@ -273,7 +300,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("kernel_sources_sha256_16") == kernel_sources_hash() and tj.get("ef_search") == ef and tj.get("n") == N and tj.get("queries") == Q:
+                if args.config == "c2" and tj.get("kernel_sources_sha256_16") == kernel_sources_hash() and tj.get("ef_search") == ef and tj.get("n") == N and tj.get("queries") == Q:
                     traffic = tj.get("hbm_bytes_per_launch")
                     traffic_note = f"{tj.get('kernel')}, measured by {tj.get('command')}"
             except Exception:
@@ -311,6 +338,103 @@ def main():
         print(json.dumps(result), flush=True)
     if exchange:
         dist.destroy_process_group()
+
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X fp32 matrix peak (v_mfma_f32_32x32x2_f32), data sheet
+
+
+def bench_c4(args):
+    """10M x 768 dot product with payload filters: payload {cat: i mod 100, tier: mix(i) mod 10}; filters at 1 %, 5 %,
+    10 % and 50 % selectivity compiled to device bitmaps; 10k-query batches on device buffers.  Narrow filters (at most
+    1/8 of the rows pass) scan the passing rows in place (fp32 MFMA contraction + fused top-k + strict re-rank, rows read
+    through a row map): bound by the matrix pipes, 2 Q N_pass D flop per batch.  Wide filters walk the graph with the pass
+    bitmap as mask: bound by HBM, bytes from the kernel's own work counters (the oracle cannot build a graph this large)."""
+    import torch
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    import vectordb_amd
+    vdb = vectordb_amd.api()
+    N, D, Q, K = args.n or 10_000_000, args.dim or 768, args.queries or 10_000, args.k
+    EF = args.ef or 128
+    t0 = time.time()
+    centres = np.random.default_rng(0xC4).uniform(0, 128, size=(1024, D)).astype(np.float32)
+    seg = vdb.Segment(vdb.HNSWIndex(vdb.DistanceMetric.Dot, 16, 64, 16, D, seed=0xC4, filter_mode=vdb.FilterMode.Masked))
+    ids_all = np.arange(N, dtype=np.uint64)
+    cat = (ids_all % 100).astype(np.int64)
+    tier = (((ids_all * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(40)) % np.uint64(10)).astype(np.int64)
+    CH = 250_000
+    sample_rows = {}                                             # rows kept on the host for the recall check
+    for lo in range(0, N, CH):
+        hi = min(N, lo + CH)
+        blk = clustered(hi - lo, D, 0xC4 + 1 + lo // CH, centres)
+        blk /= np.linalg.norm(blk, axis=1, keepdims=True)         # unit rows (embedding-like)
+        got = seg.insert_batch_columns(blk, {"cat": cat[lo:hi], "tier": tier[lo:hi]})
+        assert int(got[0]) == lo + 1                             # segment ids start at 1 (segment.rs:27)
+        keep = np.nonzero((cat[lo:hi] == 7) | (tier[lo:hi] == 3))[0]
+        sample_rows[lo] = (keep + lo, blk[keep].copy())
+        log(f"  c4: {hi} / {N} points ({time.time()-t0:.0f}s)")
+    build_s = time.time() - t0
+    queries = clustered(Q, D, 0xC4 + 5000, centres); queries /= np.linalg.norm(queries, axis=1, keepdims=True)
+    kept_ids = np.concatenate([v[0] for v in sample_rows.values()]); kept = np.concatenate([v[1] for v in sample_rows.values()])
+    PV, F, Op = vdb.PayloadValue, vdb.Filter, vdb.ScalarComparisonOp
+    cases = [("cat == 7 (1 %)", F.Match("cat", PV.Int(7)), cat == 7),
+             ("tier == 3 and cat < 50 (5 %)", F.And([F.Match("tier", PV.Int(3)), F.Compare("cat", Op.Lt, PV.Int(50))]), (tier == 3) & (cat < 50)),
+             ("tier == 3 (10 %)", F.Match("tier", PV.Int(3)), tier == 3),
+             ("cat < 50 (50 %)", F.Compare("cat", Op.Lt, PV.Int(50)), cat < 50)]
+    stream = torch.cuda.Stream(device=dev); sp = stream.cuda_stream
+    d_q = torch.from_numpy(queries).to(dev)
+    d_out = torch.zeros(Q * K * 16, dtype=torch.uint8, device=dev); d_n = torch.zeros(Q, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(Q * 4, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    info = seg.hnsw().device_info()
+    results = []
+    SAMPLE = 200                                                  # queries of the recall check (float64 brute force on the host)
+    for name, f, mask in cases:
+        t0 = time.perf_counter()
+        n_pass, n_err = seg.compile_filter(f)
+        compile_ms = (time.perf_counter() - t0) * 1e3
+        call = lambda: vdb.check(vdb.fn.segment_search_batch_dev(seg._h, d_q.data_ptr(), Q, K, EF, f._h, d_out.data_ptr(), d_n.data_ptr(), d_st.data_ptr(), sp))
+        for _ in range(max(1, args.warmup)): call()
+        stream.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(args.steps): call()
+        e1.record(stream); stream.synchronize()
+        ms = e0.elapsed_time(e1) / args.steps
+        out = d_out.cpu().numpy().view(vdb.SCORED_DTYPE).reshape(Q, K); cnt = d_n.cpu().numpy().view(np.uint32)
+        st = d_st.cpu().numpy().view(vdb.STATS_DTYPE).reshape(Q)
+        rows = out["id"].astype(np.int64) - 1
+        all_pass = bool(all(mask[rows[i][: cnt[i]]].all() for i in range(0, Q, 37)))
+        rec = None
+        sel = mask[kept_ids]
+        if sel.sum() == mask.sum():                              # the passing rows are among those kept on the host
+            sub = kept[sel].astype(np.float64); sub_ids = kept_ids[sel]
+            top = np.argpartition(-(queries[:SAMPLE].astype(np.float64) @ sub.T), K, axis=1)[:, :K]
+            rec = float(np.mean([len(set(rows[i][: cnt[i]].tolist()) & set(sub_ids[top[i]].tolist())) / K for i in range(SAMPLE)]))
+        scanned = int(st["rows_scored"].sum()) == 0
+        r = {"filter": name, "passing_rows": int(n_pass), "compile_ms_first_call": round(compile_ms, 2), "ms_per_batch": ms, "queries_per_s": Q / (ms * 1e-3),
+             "path": "scan of the passing rows (MFMA fp32 + strict re-rank)" if scanned else "masked graph walk", "mean_results": float(cnt.mean()),
+             "all_results_pass_filter": all_pass, "recall_at_10_vs_float64_brute_force": rec}
+        if scanned:
+            tf = 2.0 * Q * n_pass * D / (ms * 1e-3) / 1e12
+            r["roofline"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
+                             "hbm_bytes_algorithmic": 4.0 * n_pass * D + N / 8}
+        else:
+            b = float(st["rows_scored"].astype(np.float64).sum() * (4 * info["row_stride_floats"] + 0.125) + st["adj_entries"].astype(np.float64).sum() * 4 + st["expanded"].astype(np.float64).sum() * 8)
+            gbs = b / (ms * 1e-3) / 1e9
+            r["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                             "rows_scored_per_query": float(st["rows_scored"].mean()), "bytes_from": "the kernel's own work counters"}
+        results.append(r)
+        log(f"  c4 {name}: {r['path']}, {ms:.2f} ms per {Q} queries = {r['queries_per_s']:.0f} q/s, roofline {r['roofline']['frac']:.3f} ({r['roofline']['bound']}), recall {rec}")
+    head = results[2]
+    line = {"metric": "queries/sec, 10M x 768 dot product with a payload filter (10 % of the rows pass)", "value": head["queries_per_s"], "unit": "queries/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_batch"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"embedding-shape synthetic: {N} x {D} fp32 dot product (unit rows, 1024 Gaussian centres), payload {{cat: i mod 100, tier: mix(i) mod 10}}, "
+                                   f"{Q}-query device-buffer batches, HNSW M=16 ef_construction=64 ef_search={EF}, top-{K}, masked filter mode",
+                       "filters": results, "segment_build_seconds": round(build_s, 1), "device_bytes": info["bytes_total"]},
+            "roofline": head["roofline"]}
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

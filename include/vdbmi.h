@@ -310,6 +310,11 @@ vdb_status vdb_segment_insert(vdb_segment* s, const float* v, size_t len, const 
 /* Batched insert (extension; payloads[i] may be NULL, payloads itself may be NULL). */
 vdb_status vdb_segment_insert_batch(vdb_segment* s, const float* v, size_t n, size_t len,
                                     const vdb_payload* const* payloads, uint64_t* out_ids);
+/* Batched insert with the payloads given as columns (extension; the bulk form of Payload::set, payload.rs:27-29):
+ * every point gets the n_keys fields keys[j] -> cols[j][i]; kinds[j] is VDB_T_INT (cols[j] = int64_t[n]),
+ * VDB_T_FLOAT (double[n]) or VDB_T_BOOL (uint8_t[n]).  Same result as vdb_segment_insert_batch with such payloads. */
+vdb_status vdb_segment_insert_batch_columns(vdb_segment* s, const float* v, size_t n, size_t len, size_t n_keys,
+                                            const char* const* keys, const int32_t* kinds, const void* const* cols, uint64_t* out_ids);
 vdb_status vdb_segment_get_vector(const vdb_segment* s, uint64_t id, float* out, size_t cap);     /* segment.rs:64-69 */
 vdb_status vdb_segment_delete(vdb_segment* s, uint64_t id);                                       /* segment.rs:71-99 */
 vdb_status vdb_segment_search(const vdb_segment* s, const float* q, size_t len, size_t top_k,
@@ -339,7 +344,8 @@ vdb_status vdb_segment_in_place_filtered_search(const vdb_segment* s, const floa
  * filter the segment must be in VDB_FILTER_MASKED mode (the literal walk of hnsw.rs:585-689 picks its entry and
  * reports filter errors on the host). */
 vdb_status vdb_segment_search_batch_dev(const vdb_segment* s, const float* d_queries, size_t nq, size_t top_k,
-                                        size_t ef_search, const vdb_filter* f, vdb_scored_point* d_out, uint32_t* d_out_n, void* stream);
+                                        size_t ef_search, const vdb_filter* f, vdb_scored_point* d_out, uint32_t* d_out_n,
+                                        vdb_query_stats* d_stats /* nullable; zeros when the passing rows were scanned */, void* stream);
 /* Compile a filter to its device bitmaps (pass / error bits per slot) and return the number of
  * passing live points (extension; searches do this on demand and cache the result).  The tree of
  * filters.rs:23-75 is evaluated on the GPU over the segment's payload columns: Match on a scalar scatters the

@@ -140,7 +140,7 @@ def test_filtered_search_on_device_buffers_equals_the_host_buffer_call(vdb, metr
         want, want_n = seg.search_batch(q, k, ef_search=96, filter=f)
         out = torch.zeros(nq * k * 16, dtype=torch.uint8, device=dev); cnt = torch.full((nq,), -1, dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
-        vdb.check(vdb.fn.segment_search_batch_dev(seg._h, dq.data_ptr(), nq, k, 96, f._h if f else None, out.data_ptr(), cnt.data_ptr(), None))
+        vdb.check(vdb.fn.segment_search_batch_dev(seg._h, dq.data_ptr(), nq, k, 96, f._h if f else None, out.data_ptr(), cnt.data_ptr(), None, None))
         torch.cuda.synchronize()
         got = out.cpu().numpy().view(vdb.SCORED_DTYPE).reshape(nq, k); got_n = cnt.cpu().numpy().view(np.uint32)
         assert np.array_equal(want_n, got_n)
@@ -151,6 +151,27 @@ def test_filtered_search_on_device_buffers_equals_the_host_buffer_call(vdb, metr
     lit.insert_batch(x[:500], pay[:500])
     out = torch.zeros(nq * k * 16, dtype=torch.uint8, device=dev); cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
     with pytest.raises(vdb.ArgumentError, match="MASKED"):
-        vdb.check(vdb.fn.segment_search_batch_dev(lit._h, dq.data_ptr(), nq, k, 0, cases[1]._h, out.data_ptr(), cnt.data_ptr(), None))
-    vdb.check(vdb.fn.segment_search_batch_dev(lit._h, dq.data_ptr(), nq, k, 0, None, out.data_ptr(), cnt.data_ptr(), None))
+        vdb.check(vdb.fn.segment_search_batch_dev(lit._h, dq.data_ptr(), nq, k, 0, cases[1]._h, out.data_ptr(), cnt.data_ptr(), None, None))
+    vdb.check(vdb.fn.segment_search_batch_dev(lit._h, dq.data_ptr(), nq, k, 0, None, out.data_ptr(), cnt.data_ptr(), None, None))
     torch.cuda.synchronize()
+
+
+def test_payload_columns_build_the_same_segment_as_payload_objects(vdb):
+    n, d = 2000, 16
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(n, d)).astype(np.float32)
+    cat = (np.arange(n) % 13).astype(np.int64); w = (np.arange(n) % 4).astype(np.float64) * 0.5; odd = np.arange(n) % 2 == 1
+    def seg(): return vdb.Segment(vdb.HNSWIndex(2, 8, 32, 16, d, seed=6, filter_mode=vdb.FilterMode.Masked))
+    a, b = seg(), seg()
+    pay = []
+    for i in range(n):
+        p = vdb.Payload(); p.set("cat", vdb.PayloadValue.Int(int(cat[i]))); p.set("w", vdb.PayloadValue.Float(float(w[i]))); p.set("odd", vdb.PayloadValue.Bool(bool(odd[i]))); pay.append(p)
+    ia = a.insert_batch(x, pay); ib = b.insert_batch_columns(x, {"cat": cat, "w": w, "odd": odd})
+    assert np.array_equal(ia, ib)
+    ga, gb = a.hnsw().export_graph(), b.hnsw().export_graph()
+    for (o1, f1, n1), (o2, f2, n2) in zip(ga["layers"], gb["layers"]):
+        assert np.array_equal(o1, o2) and np.array_equal(f1, f2) and np.array_equal(n1, n2)
+    f = vdb.Filter.And([vdb.Filter.Match("odd", vdb.PayloadValue.Bool(True)), vdb.Filter.Compare("w", vdb.ScalarComparisonOp.Gte, vdb.PayloadValue.Float(1.0))])
+    assert a.compile_filter(f) == b.compile_filter(f) == (int(((np.arange(n) % 2 == 1) & (w >= 1.0)).sum()), 0)
+    pa, ea = a.filter_bitmaps(f); pb, eb = b.filter_bitmaps(f)
+    assert np.array_equal(pa, pb) and not ea.any() and not eb.any()

@@ -197,7 +197,8 @@ _SIGS = {
     "segment_in_place_filtered_search": (_I, [_VP, _VP, _SZ, _SZ, _VP, _VP, _PSZ]),
     "segment_compile_filter": (_I, [_VP, _VP, _PSZ, _PSZ]),
     "segment_filter_bitmaps": (_I, [_VP, _VP, _VP, _VP, _SZ]),
-    "segment_search_batch_dev": (_I, [_VP, _VP, _SZ, _SZ, _SZ, _VP, _VP, _VP, _VP]),
+    "segment_search_batch_dev": (_I, [_VP, _VP, _SZ, _SZ, _SZ, _VP, _VP, _VP, _VP, _VP]),
+    "segment_insert_batch_columns": (_I, [_VP, _VP, _SZ, _SZ, _SZ, _VP, _VP, _VP, _VP]),
     "topk_merge_dev": (_I, [_VP, _VP, _SZ, _SZ, _SZ, _VP, _VP, _VP]),
     "score_scan_dev": (_I, [_VP, _SZ, _VP, _SZ, _SZ, _SZ, _I, _I, _VP, _VP]),
     "default_options": (None, [_VP]),
@@ -526,6 +527,21 @@ def bind(cdll, prefix="vdb_", required=None):
             if payloads is not None:
                 arr = (C.c_void_p * n)(*[p._h if p is not None else None for p in payloads])
             check(fn.segment_insert_batch(self._h, _ptr(v), n, v.shape[1], C.cast(arr, _VP) if arr is not None else None, _ptr(out)))
+            return out
+        def insert_batch_columns(self, vectors, columns):
+            """columns: {key: int64 / float64 / bool array of one value per point}."""
+            v = _f32(vectors); n = v.shape[0]; out = np.zeros(n, np.uint64)
+            keys, kinds, cols = [], [], []
+            for k, a in columns.items():
+                a = np.asarray(a)
+                if a.dtype == np.bool_: kinds.append(3); a = np.ascontiguousarray(a, np.uint8)
+                elif np.issubdtype(a.dtype, np.integer): kinds.append(0); a = np.ascontiguousarray(a, np.int64)
+                else: kinds.append(1); a = np.ascontiguousarray(a, np.float64)
+                assert a.shape == (n,)
+                keys.append(k.encode()); cols.append(a)
+            ka = (C.c_char_p * max(len(keys), 1))(*keys); kk = np.asarray(kinds, np.int32)
+            ca = (C.c_void_p * max(len(cols), 1))(*[a.ctypes.data for a in cols])
+            check(fn.segment_insert_batch_columns(self._h, _ptr(v), n, v.shape[1], len(keys), C.cast(ka, _VP), _ptr(kk), C.cast(ca, _VP), _ptr(out)))
             return out
         def get_vector(self, id):
             out = np.zeros(self.hnsw().dim(), dtype=np.float32)

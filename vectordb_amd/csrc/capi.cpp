@@ -443,6 +443,31 @@ vdb_status vdb_segment_insert(vdb_segment* s, const float* v, size_t len, const 
 vdb_status vdb_segment_insert_batch(vdb_segment* s, const float* v, size_t n, size_t len, const vdb_payload* const* p, uint64_t* out_ids) {
     return guard([&] { need(s, "segment"); if (n) need(v, "vectors"); s->insert_batch(v, n, len, p, out_ids); });
 }
+vdb_status vdb_segment_insert_batch_columns(vdb_segment* s, const float* v, size_t n, size_t len, size_t n_keys, const char* const* keys,
+                                            const int32_t* kinds, const void* const* cols, uint64_t* out_ids) {
+    return guard([&] {
+        need(s, "segment"); if (n) need(v, "vectors");
+        if (n_keys) { need(keys, "keys"); need(kinds, "kinds"); need(cols, "cols"); }
+        for (size_t j = 0; j < n_keys; ++j) {
+            need(keys[j], "keys[j]"); need(cols[j], "cols[j]");
+            if (kinds[j] != VDB_T_INT && kinds[j] != VDB_T_FLOAT && kinds[j] != VDB_T_BOOL) throw Failure(err_arg("payload columns hold Int, Float or Bool values"));
+        }
+        std::vector<vdb_payload> pays(n_keys ? n : 0);
+        for (size_t j = 0; j < n_keys; ++j) {
+            const std::string key(keys[j]);
+            for (size_t i = 0; i < n; ++i) {
+                vdb_value val;
+                if (kinds[j] == VDB_T_INT) val.d = static_cast<const int64_t*>(cols[j])[i];
+                else if (kinds[j] == VDB_T_FLOAT) val.d = OF64{static_cast<const double*>(cols[j])[i]};
+                else val.d = Bool8{(uint8_t)(static_cast<const uint8_t*>(cols[j])[i] != 0)};
+                pays[i].set(key, val);
+            }
+        }
+        std::vector<const vdb_payload*> ptrs(pays.size());
+        for (size_t i = 0; i < pays.size(); ++i) ptrs[i] = &pays[i];
+        s->insert_batch(v, n, len, n_keys ? ptrs.data() : nullptr, out_ids);
+    });
+}
 vdb_status vdb_segment_get_vector(const vdb_segment* s, uint64_t id, float* out, size_t cap) {
     return guard([&] {
         need(s, "segment"); need(out, "out");
@@ -491,12 +516,12 @@ vdb_status vdb_segment_filter_bitmaps(const vdb_segment* s, const vdb_filter* f,
     });
 }
 vdb_status vdb_segment_search_batch_dev(const vdb_segment* s, const float* d_q, size_t nq, size_t top_k, size_t ef_search, const vdb_filter* f,
-                                        vdb_scored_point* d_out, uint32_t* d_out_n, void* stream) {
+                                        vdb_scored_point* d_out, uint32_t* d_out_n, vdb_query_stats* d_stats, void* stream) {
     return guard([&] {
         need(s, "segment");
         if (nq == 0) return;
         need(d_q, "d_queries"); need(d_out, "d_out"); need(d_out_n, "d_out_n");
-        s->search_batch_dev(d_q, nq, top_k, ef_search, f, d_out, d_out_n, (hipStream_t)stream);
+        s->search_batch_dev(d_q, nq, top_k, ef_search, f, d_out, d_out_n, d_stats, (hipStream_t)stream);
     });
 }
 

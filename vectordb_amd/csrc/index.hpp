@@ -200,7 +200,7 @@ struct vdb_segment {
                       vdb_scored_point* out, uint32_t* out_n) const;
     // the same on device buffers, enqueued on `s` without a host synchronisation (masked filter mode when f is given)
     void search_batch_dev(const float* d_q, size_t nq, size_t top_k, size_t ef_search, const vdb_filter* f,
-                          vdb_scored_point* d_out, uint32_t* d_out_n, hipStream_t s) const;
+                          vdb_scored_point* d_out, uint32_t* d_out_n, vdb_query_stats* d_stats, hipStream_t s) const;
     std::shared_ptr<const vdb::FilterBits> compile(const vdb_filter& f) const;
     // host copies of a compiled filter's bitmaps ((len + 31) / 32 words each): what the tests compare with evaluate_filter
     void filter_bitmaps(const vdb_filter& f, uint32_t* pass, uint32_t* err) const;

@@ -679,18 +679,21 @@ void vdb_segment::search_batch(const float* q, size_t nq, size_t len, size_t top
 // Batched Segment::search / search_with_filter on device buffers.  The graph walk never returns a tombstone (hnsw.rs:475)
 // and the scan reads live rows only, so the over-fetch of segment.rs:110 / :134 changes nothing here and is left out.
 void vdb_segment::search_batch_dev(const float* d_q, size_t nq, size_t top_k, size_t ef_search, const vdb_filter* f,
-                                   vdb_scored_point* d_out, uint32_t* d_out_n, hipStream_t s) const {
+                                   vdb_scored_point* d_out, uint32_t* d_out_n, vdb_query_stats* d_stats, hipStream_t s) const {
     if (live_count() == 0) throw Failure(err_search("No active points available to search."));
     vdb_index& h = *hnsw;
-    if (!f) { h.search_batch_dev(d_q, nq, top_k, ef_search, d_out, d_out_n, nullptr, s); return; }
+    if (!f) { h.search_batch_dev(d_q, nq, top_k, ef_search, d_out, d_out_n, d_stats, s); return; }
     if (h.opts.filter_mode != VDB_FILTER_MASKED)
         throw Failure(err_arg("filtered search on device buffers needs filter_mode = VDB_FILTER_MASKED (the literal walk picks its entry and reports errors on the host)"));
     const std::shared_ptr<const FilterBits> bits = compile(*f);
     if (bits->n_pass == 0) { h.use_device(); VDB_HIP(hipMemsetAsync(d_out_n, 0, nq * sizeof(uint32_t), s ? s : h.stream)); return; }
-    if (bits->have_rows && masked_scan_pays(bits->n_pass, h.len())) { h.exact_knn(d_q, nq, top_k, true, d_out, d_out_n, s, bits->d_rows.p, bits->n_pass); }
+    if (bits->have_rows && masked_scan_pays(bits->n_pass, h.len())) {
+        h.exact_knn(d_q, nq, top_k, true, d_out, d_out_n, s, bits->d_rows.p, bits->n_pass);
+        if (d_stats) VDB_HIP(hipMemsetAsync(d_stats, 0, nq * sizeof(vdb_query_stats), s ? s : h.stream));    // a scan walks no graph
+    }
     else {
         vdb_index::FilterArgs fa; fa.mode = MODE_MASKED; fa.bits = bits.get();
-        h.search_batch_dev(d_q, nq, top_k, ef_search, d_out, d_out_n, nullptr, s, &fa);
+        h.search_batch_dev(d_q, nq, top_k, ef_search, d_out, d_out_n, d_stats, s, &fa);
     }
     // the bitmaps must outlive the launches: the cache holds them, and an evicted entry is kept until the stream has drained
     h.use_device();
