@@ -294,6 +294,17 @@ vdb_status vdb_index_export_layer(const vdb_index* x, size_t level, uint32_t* ow
  * is VDB_ERR_ARGUMENT and leaves the index as it was. */
 vdb_status vdb_index_save(const vdb_index* x, const char* path);
 vdb_status vdb_index_load(vdb_index* x, const char* path);
+/* Segment file (extension; the state of segment.rs:11-18 on disk): the graph file of the segment's index, followed by
+ *   char magic[8] = "VDBSEGM1"; u64 next_id, n_deleted, n_payloads; u64 deleted_ids[n_deleted] (ascending);
+ *   per payload, ascending id: u64 id, n_fields; per field (ascending key): string key; u64 kind (vdb_value_kind); value:
+ *     Int i64 | Float f64 | Bool u64 | Str string | ListInt u64 n + i64[n] | ListFloat u64 n + f64[n] |
+ *     ListStr u64 n + n strings | ListBool u64 n + u8[n];  string = u64 length + bytes; everything padded to 8 bytes.
+ * vdb_index_load reads the index part of such a file.  vdb_segment_load replaces the contents of a segment whose
+ * index was created with the same metric and dimension: vectors, lists, tombstones, payloads, deleted set, next_id and
+ * the random streams; the inverted index is rebuilt from the payloads of the live points.  Errors as for the graph file;
+ * the segment is untouched unless the whole file was read and found consistent. */
+vdb_status vdb_segment_save(const vdb_segment* s, const char* path);
+vdb_status vdb_segment_load(vdb_segment* s, const char* path);
 /* Device-side footprint of the packed graph actually searched (after self-loop / duplicate removal). */
 vdb_status vdb_index_device_info(const vdb_index* x, size_t* n_slots, size_t* row_stride_floats,
                                  size_t* l0_edges, size_t* upper_edges, size_t* bytes_total);

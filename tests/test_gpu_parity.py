@@ -630,3 +630,22 @@ def test_masked_walk_on_the_register_beam(ora, vdb, monkeypatch, metric):
             row = out["id"][i][: cnt[i]].tolist()
             assert len(set(row)) == len(row) and set(row) <= odd
             assert np.all(np.diff(out["sort_key"][i][: cnt[i]]) >= 0)
+
+
+def test_literal_filtered_search_beyond_the_old_queue_size_matches_the_oracle(ora, vdb):
+    """hnsw.rs:639-689 never prunes its candidate heap; the walk visits every reachable row once ef passing rows are
+    known.  A segment of 18 000 rows (the candidate queue used to stop at 16 384 entries) built point by point on both
+    sides: same results as the oracle's literal walk, worst-first order and equal-key order included."""
+    n, d, k = 18_000, 8, 10
+    x = data(n, d, 171); q = data(6, d, 172)
+    so = _payload_segment(ora, 2, x, ora.FilterMode.Literal)
+    sp = _payload_segment(vdb, 2, x, vdb.FilterMode.Literal, arith=vdb.Arith.Strict)
+    for make in (lambda a: a.Filter.Match("half", a.PayloadValue.Int(1)), lambda a: a.Filter.Match("cat", a.PayloadValue.Int(3))):
+        for qi in range(len(q)):
+            ref = so.in_place_filtered_search(q[qi], k, make(ora)); got = sp.in_place_filtered_search(q[qi], k, make(vdb))
+            assert [r.id for r in ref] == [g.id for g in got]
+            assert [np.float32(r.sort_key).view(np.uint32) for r in ref] == [np.float32(g.sort_key).view(np.uint32) for g in got]
+    out, cnt = sp.search_batch(q, 5, filter=vdb.Filter.Match("half", vdb.PayloadValue.Int(0)))       # the batched form, several queries per launch
+    for qi in range(len(q)):
+        one = sp.search_with_filter(q[qi], 5, vdb.Filter.Match("half", vdb.PayloadValue.Int(0)))
+        assert [r.id for r in one] == out["id"][qi][: cnt[qi]].tolist()

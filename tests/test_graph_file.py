@@ -146,3 +146,81 @@ def test_bad_graphs_and_files_are_rejected_and_leave_the_index_untouched(ora, vd
         hp.load(tmp_path / "huge")
     got, gotn = hp.search_batch(q, 5)
     assert np.array_equal(refn, gotn) and np.array_equal(ref["id"], got["id"])
+
+
+def _seg_payload(api, i):
+    p = api.Payload()
+    p.set("cat", api.PayloadValue.Int(i % 5)); p.set("w", api.PayloadValue.Float(0.25 * (i % 7)))
+    if i % 3 == 0: p.set("name", api.PayloadValue.Str(["a", "bb", "ccc é"][i % 9 // 3]))
+    if i % 4 == 0: p.set("on", api.PayloadValue.Bool(i % 8 == 0))
+    if i % 10 == 0: p.set("tags", api.PayloadValue.ListStr(["x", "yy"][: 1 + i % 20 // 10]))
+    if i % 25 == 0: p.set("nums", api.PayloadValue.ListInt([i, -i])); p.set("fs", api.PayloadValue.ListFloat([0.5 * i])); p.set("bs", api.PayloadValue.ListBool([True, False]))
+    return p
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric", [0, 2])
+def test_a_saved_and_loaded_segment_answers_and_grows_like_the_original(ora, vdb, tmp_path, metric):
+    """vdb_segment_save / vdb_segment_load: the loaded segment holds the same payloads, tombstones and next id, answers
+    search_with_filter bit-identically, and further inserts build the graph the oracle's segment builds from the same
+    history (same seed, STRICT arithmetic) — the random streams continue across the file."""
+    n, extra, d = 260, 40, 10
+    rng = np.random.default_rng(70 + metric)
+    x = rng.uniform(-1, 1, size=(n + extra, d)).astype(np.float32)
+    def fresh(api, seed=8, **kw): return api.Segment(api.HNSWIndex(metric, 8, 32, 16, d, seed=seed, **kw))
+    so, sv = fresh(ora), fresh(vdb, arith=vdb.Arith.Strict)
+    for i in range(n):
+        a = so.insert(x[i], _seg_payload(ora, i) if i % 6 else None); b = sv.insert(x[i], _seg_payload(vdb, i) if i % 6 else None)
+        assert a == b
+    for i in (3, 50, 51, 200):
+        so.delete(i + 1); sv.delete(i + 1)
+    path = tmp_path / "seg.vdbseg"
+    sv.save(path)
+    # the file as the Python reader sees it
+    cfg, g, seg = graph_file.read_segment(path)
+    assert seg["next_id"] == n + 1 and seg["deleted"] == [4, 51, 52, 201] and len(seg["payloads"]) == sv.payload_count()
+    assert seg["payloads"][1]["cat"] == ("Int", 0) and seg["payloads"][26]["nums"] == ("ListInt", [25, -25]) and seg["payloads"][10]["name"] == ("Str", "ccc é")
+    assert cfg["dim"] == d and len(g["ids"]) == n
+    # loaded into a segment created with another seed: everything comes from the file
+    sl = fresh(vdb, seed=99, arith=vdb.Arith.Strict)
+    sl.load(path)
+    assert sl.payload_count() == sv.payload_count() and sl.is_deleted(51) and not sl.is_deleted(2) and sl.get_vector(4) is None
+    assert sl.payload_index().query_exact("cat", vdb.PayloadValue.Int(2)) == sv.payload_index().query_exact("cat", vdb.PayloadValue.Int(2))
+    V, F, Op = vdb.PayloadValue, vdb.Filter, vdb.ScalarComparisonOp
+    VO, FO, OpO = ora.PayloadValue, ora.Filter, ora.ScalarComparisonOp
+    flt = lambda A, B, C: [None, A.Match("cat", B.Int(3)), A.And([A.Compare("w", C.Gte, B.Float(0.5)), A.Not(A.Match("name", B.Str("bb")))]), A.Compare("tags", C.Eq, B.Str("yy"))]
+    def same(a, b):
+        assert [r.id for r in a] == [r.id for r in b] and [np.float32(r.sort_key).view(np.uint32) for r in a] == [np.float32(r.sort_key).view(np.uint32) for r in b]
+    for fv, fo in zip(flt(F, V, Op), flt(FO, VO, OpO)):
+        for qi in range(0, n, 23):
+            for call in ("search_with_filter", "post_filter"):
+                try: want = getattr(so, call)(x[qi], 5, fo)
+                except ora.DBError as e: want = type(e).__name__
+                try: got = getattr(sl, call)(x[qi], 5, fv)
+                except vdb.DBError as e: got = type(e).__name__
+                if isinstance(want, str) or isinstance(got, str): assert want == got
+                else: same(want, got)
+    # the history continues identically: ids, graph, results
+    for i in range(n, n + extra):
+        a = so.insert(x[i], _seg_payload(ora, i)); b = sl.insert(x[i], _seg_payload(vdb, i)); c = sv.insert(x[i], _seg_payload(vdb, i))
+        assert a == b == c
+    _same_graph(so.hnsw().export_graph(), sl.hnsw().export_graph())
+    _same_graph(sv.hnsw().export_graph(), sl.hnsw().export_graph())
+    # damaged files leave the segment as it was
+    raw = path.read_bytes()
+    (tmp_path / "cut").write_bytes(raw[:-20])
+    with pytest.raises(vdb.DBError):
+        sl.load(tmp_path / "cut")
+    at = raw.index(b"VDBSEGM1")
+    (tmp_path / "magic").write_bytes(raw[:at] + b"VDBSEGMX" + raw[at + 8:])
+    with pytest.raises(vdb.ArgumentError):
+        sl.load(tmp_path / "magic")
+    bad = bytearray(raw); bad[at + 32: at + 40] = np.uint64(123456).tobytes()        # first deleted id: not a tombstone of the index
+    (tmp_path / "del").write_bytes(bytes(bad))
+    with pytest.raises(vdb.ArgumentError):
+        sl.load(tmp_path / "del")
+    assert sl.hnsw().len() == n + extra and sl.payload_count() == sv.payload_count()
+    same(sl.search(x[7], 5), sv.search(x[7], 5))
+    # an index file loads the index part of a segment file
+    hi = vdb.HNSWIndex(metric, 8, 32, 16, d, arith=vdb.Arith.Strict); hi.load(path)
+    assert hi.len() == n

@@ -196,6 +196,7 @@ _SIGS = {
     "segment_payload_index": (_VP, [_VP]), "segment_payload_count": (_SZ, [_VP]),
     "segment_in_place_filtered_search": (_I, [_VP, _VP, _SZ, _SZ, _VP, _VP, _PSZ]),
     "segment_compile_filter": (_I, [_VP, _VP, _PSZ, _PSZ]),
+    "segment_save": (_I, [_VP, C.c_char_p]), "segment_load": (_I, [_VP, C.c_char_p]),
     "segment_filter_bitmaps": (_I, [_VP, _VP, _VP, _VP, _SZ]),
     "segment_search_batch_dev": (_I, [_VP, _VP, _SZ, _SZ, _SZ, _VP, _VP, _VP, _VP, _VP]),
     "segment_insert_batch_columns": (_I, [_VP, _VP, _SZ, _SZ, _SZ, _VP, _VP, _VP, _VP]),
@@ -579,6 +580,8 @@ def bind(cdll, prefix="vdb_", required=None):
             a, b = C.c_size_t(0), C.c_size_t(0)
             check(fn.segment_compile_filter(self._h, filter._h, C.byref(a), C.byref(b)))
             return a.value, b.value
+        def save(self, path): check(fn.segment_save(self._h, str(path).encode()))
+        def load(self, path): check(fn.segment_load(self._h, str(path).encode()))
         def filter_bitmaps(self, filter):
             """-> (pass, err) as bool arrays over the slots (insertion order)."""
             n = self.hnsw().len(); words = (n + 31) // 32

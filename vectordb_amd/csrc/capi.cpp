@@ -368,46 +368,44 @@ struct File {
     }
 };
 }  // namespace
-vdb_status vdb_index_save(const vdb_index* x, const char* path) {
-    return guard([&] {
-        need(x, "index"); need(path, "path");
-        File out(path, "wb");
-        GraphFileHeader h{};
-        std::memcpy(h.magic, GRAPH_MAGIC, 8); h.version = 1; h.metric = (uint32_t)x->metric;
-        h.m = x->m; h.ef = x->ef; h.max_level_cap = x->max_level_cap; h.dim = x->dim; h.n = x->len(); h.n_layers = x->layers.size();
-        h.has_entry = x->entry_point ? 1 : 0; h.entry_id = x->entry_point ? *x->entry_point : 0; h.current_max_level = x->current_max_level;
-        h.level_draws = x->level_draws; h.sample_draws = x->sample_draws; h.seed = x->opts.seed;
-        out.put(&h, sizeof h);
-        out.put(x->ids.data(), h.n * 8); out.put(x->levels.data(), h.n * 4); out.put(x->deleted.data(), h.n);
-        out.put(x->hvecs.data(), h.n * x->dim * 4);
-        for (size_t l = 0; l < x->layers.size(); ++l) {
-            size_t n_lists = 0, n_edges = 0;
-            n_lists = x->layers[l].lists.size(); for (auto& v : x->layers[l].lists) n_edges += v.size();
-            std::vector<uint32_t> owners(n_lists), nb(std::max<size_t>(n_edges, 1)); std::vector<uint64_t> off(n_lists + 1);
-            if (vdb_index_export_layer(x, l, owners.data(), off.data(), nb.data()) != VDB_OK) throw Failure(err_arg(vdb_last_error_message()));
-            const uint64_t cnt[2] = {n_lists, n_edges};
-            out.put(cnt, 16); out.put(owners.data(), n_lists * 4); out.put(off.data(), (n_lists + 1) * 8); out.put(nb.data(), n_edges * 4);
-        }
-        out.close();
-    });
+extern "C++" {
+namespace {
+void write_index(File& out, const vdb_index* x) {
+    GraphFileHeader h{};
+    std::memcpy(h.magic, GRAPH_MAGIC, 8); h.version = 1; h.metric = (uint32_t)x->metric;
+    h.m = x->m; h.ef = x->ef; h.max_level_cap = x->max_level_cap; h.dim = x->dim; h.n = x->len(); h.n_layers = x->layers.size();
+    h.has_entry = x->entry_point ? 1 : 0; h.entry_id = x->entry_point ? *x->entry_point : 0; h.current_max_level = x->current_max_level;
+    h.level_draws = x->level_draws; h.sample_draws = x->sample_draws; h.seed = x->opts.seed;
+    out.put(&h, sizeof h);
+    out.put(x->ids.data(), h.n * 8); out.put(x->levels.data(), h.n * 4); out.put(x->deleted.data(), h.n);
+    out.put(x->hvecs.data(), h.n * x->dim * 4);
+    for (size_t l = 0; l < x->layers.size(); ++l) {
+        size_t n_lists = 0, n_edges = 0;
+        n_lists = x->layers[l].lists.size(); for (auto& v : x->layers[l].lists) n_edges += v.size();
+        std::vector<uint32_t> owners(n_lists), nb(std::max<size_t>(n_edges, 1)); std::vector<uint64_t> off(n_lists + 1);
+        if (vdb_index_export_layer(x, l, owners.data(), off.data(), nb.data()) != VDB_OK) throw Failure(err_arg(vdb_last_error_message()));
+        const uint64_t cnt[2] = {n_lists, n_edges};
+        out.put(cnt, 16); out.put(owners.data(), n_lists * 4); out.put(off.data(), (n_lists + 1) * 8); out.put(nb.data(), n_edges * 4);
+    }
 }
-vdb_status vdb_index_load(vdb_index* x, const char* path) {
-    return guard([&] {
-        need(x, "index"); need(path, "path");
-        File in(path, "rb");
-        GraphFileHeader h{};
+// The index part of a file, read and checked against the handle it is meant for; nothing is applied yet.
+struct IndexImage {
+    GraphFileHeader h{};
+    std::vector<uint64_t> ids; std::vector<uint32_t> levels; std::vector<uint8_t> del; std::vector<float> vecs;
+    std::vector<std::vector<uint32_t>> owners, nbs; std::vector<std::vector<uint64_t>> offs; std::vector<vdb_layer_csr> csr;
+    uint64_t file_bytes = 0;
+    void read(File& in, const vdb_index* x) {
         in.get(&h, sizeof h);
         if (std::memcmp(h.magic, GRAPH_MAGIC, 8) != 0 || h.version != 1) throw Failure(err_arg(in.path + " is not a version-1 graph file"));
         if (h.metric != (uint32_t)x->metric || h.dim != x->dim)
             throw Failure(err_arg(in.path + " holds metric " + std::to_string(h.metric) + ", dimension " + std::to_string(h.dim) + "; the index was created with metric " +
                                   std::to_string((int)x->metric) + ", dimension " + std::to_string(x->dim)));
         // nothing is allocated from a count the file cannot back with bytes
-        std::fseek(in.f, 0, SEEK_END); const uint64_t file_bytes = (uint64_t)std::ftell(in.f); std::fseek(in.f, (long)sizeof h, SEEK_SET);
+        std::fseek(in.f, 0, SEEK_END); file_bytes = (uint64_t)std::ftell(in.f); std::fseek(in.f, (long)sizeof h, SEEK_SET);
         if (h.n > 0x7FFFFFF0ull || h.n_layers > 64 || h.n * (13 + 4 * h.dim) > file_bytes) throw Failure(err_arg(in.path + " has an implausible header"));
-        std::vector<uint64_t> ids(h.n); std::vector<uint32_t> levels(h.n); std::vector<uint8_t> del(h.n); std::vector<float> vecs(h.n * h.dim);
+        ids.resize(h.n); levels.resize(h.n); del.resize(h.n); vecs.resize(h.n * h.dim);
         in.get(ids.data(), h.n * 8); in.get(levels.data(), h.n * 4); in.get(del.data(), h.n); in.get(vecs.data(), h.n * h.dim * 4);
-        std::vector<std::vector<uint32_t>> owners(h.n_layers), nbs(h.n_layers); std::vector<std::vector<uint64_t>> offs(h.n_layers);
-        std::vector<vdb_layer_csr> csr(h.n_layers);
+        owners.resize(h.n_layers); nbs.resize(h.n_layers); offs.resize(h.n_layers); csr.resize(h.n_layers);
         for (size_t l = 0; l < h.n_layers; ++l) {
             uint64_t cnt[2]; in.get(cnt, 16);
             if (cnt[0] > h.n || cnt[1] > file_bytes / 4) throw Failure(err_arg(in.path + ": layer " + std::to_string(l) + " has implausible sizes"));
@@ -416,8 +414,124 @@ vdb_status vdb_index_load(vdb_index* x, const char* path) {
             if (offs[l].back() != cnt[1]) throw Failure(err_arg(in.path + ": layer " + std::to_string(l) + " offsets do not cover its neighbours"));
             csr[l] = {(size_t)cnt[0], owners[l].data(), offs[l].data(), nbs[l].data(), (size_t)cnt[1]};
         }
+    }
+    void apply(vdb_index* x) {            // import_graph validates the lists before it touches the index
         x->import_graph(h.n, ids.data(), levels.data(), vecs.data(), del.data(), h.n_layers, csr.data(), h.has_entry != 0, h.entry_id, h.current_max_level);
         x->level_draws = h.level_draws; x->sample_draws = h.sample_draws; x->opts.seed = h.seed;     // the saved build's random streams continue
+    }
+};
+constexpr char SEGMENT_MAGIC[8] = {'V', 'D', 'B', 'S', 'E', 'G', 'M', '1'};
+void put_u64(File& f, uint64_t v) { f.put(&v, 8); }
+uint64_t get_u64(File& f) { uint64_t v; f.get(&v, 8); return v; }
+void put_str(File& f, const std::string& s) { put_u64(f, s.size()); f.put(s.data(), s.size()); }
+std::string get_str(File& f, uint64_t limit) {
+    const uint64_t n = get_u64(f);
+    if (n > limit) throw Failure(err_arg(f.path + ": a string is longer than the file"));
+    std::string s(n, '\0'); f.get(s.data(), n); return s;
+}
+void put_value(File& f, const vdb_value& v) {
+    put_u64(f, (uint64_t)v.kind());
+    std::visit([&](const auto& x) {
+        using T = std::decay_t<decltype(x)>;
+        if constexpr (std::is_same_v<T, int64_t>) f.put(&x, 8);
+        else if constexpr (std::is_same_v<T, OF64>) f.put(&x.v, 8);
+        else if constexpr (std::is_same_v<T, std::string>) put_str(f, x);
+        else if constexpr (std::is_same_v<T, Bool8>) put_u64(f, x.v != 0);
+        else if constexpr (std::is_same_v<T, std::vector<int64_t>>) { put_u64(f, x.size()); f.put(x.data(), x.size() * 8); }
+        else if constexpr (std::is_same_v<T, std::vector<OF64>>) { put_u64(f, x.size()); for (auto& e : x) f.put(&e.v, 8); }
+        else if constexpr (std::is_same_v<T, std::vector<std::string>>) { put_u64(f, x.size()); for (auto& e : x) put_str(f, e); }
+        else { put_u64(f, x.size()); std::vector<uint8_t> b(x.size()); for (size_t i = 0; i < x.size(); ++i) b[i] = x[i].v != 0; f.put(b.data(), b.size()); }
+    }, v.d);
+}
+vdb_value get_value(File& f, uint64_t limit) {
+    vdb_value v;
+    const uint64_t kind = get_u64(f);
+    auto count = [&](uint64_t each) { const uint64_t n = get_u64(f); if (n > limit / each) throw Failure(err_arg(f.path + ": a list is longer than the file")); return n; };
+    switch (kind) {
+        case VDB_T_INT: { int64_t x; f.get(&x, 8); v.d = x; break; }
+        case VDB_T_FLOAT: { double x; f.get(&x, 8); v.d = OF64{x}; break; }
+        case VDB_T_STR: v.d = get_str(f, limit); break;
+        case VDB_T_BOOL: v.d = Bool8{(uint8_t)(get_u64(f) != 0)}; break;
+        case VDB_T_LIST_INT: { std::vector<int64_t> l(count(8)); f.get(l.data(), l.size() * 8); v.d = std::move(l); break; }
+        case VDB_T_LIST_FLOAT: { std::vector<OF64> l(count(8)); for (auto& e : l) f.get(&e.v, 8); v.d = std::move(l); break; }
+        case VDB_T_LIST_STR: { std::vector<std::string> l(count(8)); for (auto& e : l) e = get_str(f, limit); v.d = std::move(l); break; }
+        case VDB_T_LIST_BOOL: { std::vector<uint8_t> b(count(1)); f.get(b.data(), b.size()); std::vector<Bool8> l(b.size()); for (size_t i = 0; i < b.size(); ++i) l[i].v = b[i] != 0; v.d = std::move(l); break; }
+        default: throw Failure(err_arg(f.path + ": unknown payload value kind " + std::to_string(kind)));
+    }
+    return v;
+}
+}  // namespace
+}  // extern "C++"
+vdb_status vdb_index_save(const vdb_index* x, const char* path) {
+    return guard([&] {
+        need(x, "index"); need(path, "path");
+        File out(path, "wb");
+        write_index(out, x);
+        out.close();
+    });
+}
+vdb_status vdb_index_load(vdb_index* x, const char* path) {
+    return guard([&] {
+        need(x, "index"); need(path, "path");
+        File in(path, "rb");
+        IndexImage img; img.read(in, x);
+        img.apply(x);
+    });
+}
+vdb_status vdb_segment_save(const vdb_segment* s, const char* path) {
+    return guard([&] {
+        need(s, "segment"); need(path, "path");
+        File out(path, "wb");
+        write_index(out, s->hnsw.get());
+        out.put(SEGMENT_MAGIC, 8);
+        put_u64(out, s->next_id); put_u64(out, s->deleted.size()); put_u64(out, s->payloads.size());
+        for (uint64_t id : s->deleted) put_u64(out, id);
+        std::vector<uint64_t> order; order.reserve(s->payloads.size());
+        for (auto& kv : s->payloads) order.push_back(kv.first);
+        std::sort(order.begin(), order.end());
+        for (uint64_t id : order) {
+            const vdb_payload& p = s->payloads.at(id);
+            put_u64(out, id); put_u64(out, p.fields.size());
+            for (auto& f : p.fields) { put_str(out, f.first); put_value(out, f.second); }
+        }
+        out.close();
+    });
+}
+vdb_status vdb_segment_load(vdb_segment* s, const char* path) {
+    return guard([&] {
+        need(s, "segment"); need(path, "path");
+        File in(path, "rb");
+        IndexImage img; img.read(in, s->hnsw.get());
+        char magic[8]; in.get(magic, 8);
+        if (std::memcmp(magic, SEGMENT_MAGIC, 8) != 0) throw Failure(err_arg(in.path + " holds an index but no segment section"));
+        const uint64_t next_id = get_u64(in), n_del = get_u64(in), n_pay = get_u64(in);
+        if (n_del > img.file_bytes / 8 || n_pay > img.file_bytes / 16) throw Failure(err_arg(in.path + ": implausible segment counts"));
+        std::unordered_map<uint64_t, uint32_t> known; known.reserve(img.ids.size() * 2);
+        for (size_t i = 0; i < img.ids.size(); ++i) known.emplace(img.ids[i], (uint32_t)i);
+        std::set<uint64_t> del;
+        for (uint64_t i = 0; i < n_del; ++i) {
+            const uint64_t id = get_u64(in);
+            auto k = known.find(id);
+            if (k == known.end() || !img.del[k->second]) throw Failure(err_arg(in.path + ": deleted id " + std::to_string(id) + " is not a tombstone of the index"));
+            del.insert(id);
+        }
+        std::unordered_map<uint64_t, vdb_payload> pays; pays.reserve(n_pay * 2);
+        for (uint64_t i = 0; i < n_pay; ++i) {
+            const uint64_t id = get_u64(in), nf = get_u64(in);
+            if (nf > img.file_bytes / 16) throw Failure(err_arg(in.path + ": implausible field count"));
+            vdb_payload p;
+            for (uint64_t k = 0; k < nf; ++k) { std::string key = get_str(in, img.file_bytes); p.set(key, get_value(in, img.file_bytes)); }
+            if (!pays.emplace(id, std::move(p)).second) throw Failure(err_arg(in.path + ": payload of id " + std::to_string(id) + " occurs twice"));
+        }
+        for (uint64_t id : img.ids) if (id >= next_id) throw Failure(err_arg(in.path + ": next_id does not lie above the ids in use"));
+        // everything is read and checked: take over (a bad list still leaves index and segment as they were)
+        img.apply(s->hnsw.get());
+        s->payloads.swap(pays); s->deleted.swap(del); s->next_id = next_id;
+        s->payload_index = vdb_payload_index();
+        for (auto& kv : s->payloads) if (!s->deleted.count(kv.first) && known.count(kv.first)) s->payload_index.insert(kv.first, kv.second);   // stores.rs:18-52: live points only
+        { std::lock_guard<std::mutex> lk(s->filter_mu); s->filter_cache.clear(); }
+        ++s->payload_version;
+        s->rebuild_columns();
     });
 }
 vdb_status vdb_index_device_info(const vdb_index* x, size_t* n_slots, size_t* row_stride_floats, size_t* l0_edges, size_t* upper_edges, size_t* bytes_total) {

@@ -10,6 +10,7 @@
 using namespace vdb;
 
 namespace {
+constexpr size_t WAVE_LANES = 64;
 thread_local std::string g_last_error;
 }
 void vdb::set_last_error(const std::string& s) { g_last_error = s; }
@@ -536,6 +537,17 @@ void vdb_index::run_search(SearchArgs a, size_t nq, hipStream_t s, bool retry_on
     while (a.tag_log2 < 15 && ((uint64_t)a.g.n >> (a.tag_log2 + 13)) != 0) ++a.tag_log2;
     if (forced_tags >= 7 && forced_tags <= 15) a.tag_log2 = (uint32_t)forced_tags;      // tests shrink it to force forgetting
     if (const char* fg = getenv("VDB_FORCE_GENERIC")) { if (atoi(fg) != 0) a.force_generic = 1; }   // tests: the LDS-list kernel for every mode
+    if (a.mode == MODE_LITERAL) {
+        // the literal walk visits every reachable row: one spill table per query of the launch, sized for all rows
+        // (a pool of its own: the geometry differs from the shared one and follows the segment's size)
+        a.spill_log2 = 15;
+        while (a.spill_log2 < 30 && (size_t(3) << a.spill_log2) / 4 < (size_t)a.g.n + 4 * WAVE_LANES) ++a.spill_log2;
+        a.spill_tables = (uint32_t)nq;
+        const size_t words = (size_t)a.spill_tables + ((size_t)a.spill_tables << a.spill_log2);
+        s_spill_lit.reserve(words, s, false);
+        VDB_HIP(hipMemsetAsync(s_spill_lit.p, 0, (size_t)a.spill_tables * 4, s));
+        a.spill_locks = s_spill_lit.p; a.spill_pool = s_spill_lit.p + a.spill_tables;
+    } else {
     // one spill table per possibly resident wavefront (256 CUs x 16), 2^15 ids each
     a.spill_log2 = 15;
     a.spill_tables = 4096;
@@ -548,6 +560,7 @@ void vdb_index::run_search(SearchArgs a, size_t nq, hipStream_t s, bool retry_on
         VDB_HIP(hipStreamSynchronize(s));
     }
     a.spill_locks = s_spill.p; a.spill_pool = s_spill.p + a.spill_tables;
+    }
     launch_search(a, s);
     // the register-resident beam never overflows (its visited set forgets instead): nothing to follow up
     if (reg_list_chunks(a) > 0) return;
@@ -613,16 +626,26 @@ void vdb_index::search_batch(const float* q, size_t nq, size_t top_k, size_t ef_
     a.beam_width = beam_width();
     if (fa.bits) { a.pass_bits = fa.bits->d_pass.p; a.err_bits = fa.bits->d_err.p; }
     if (fa.mode == MODE_LITERAL) {
-        // hnsw.rs:639-689 never prunes its candidate heap: it holds every scored row that was not popped yet.
-        // The queue is an unsorted array whose minimum is found by a scan, so its size also bounds the time a
-        // query can take: 16384 entries (one per row in smaller segments); a walk that needs more is reported.
-        const char* ce = getenv("VDB_LITERAL_CAND_CAP");
-        size_t cap = 16384;
-        if (ce && atoi(ce) > 0) cap = (size_t)atoi(ce);
-        a.cand_cap = (uint32_t)std::min<size_t>(cap, ids.size() + 1);
-        s_cand.reserve(nq * a.cand_cap, stream, false);
+        // hnsw.rs:639-689 never prunes its candidate heap: it can hold every row of the segment (each row is scored at
+        // most once), so the heap of a query has room for all of them and the walk runs at any segment size.  The
+        // batch is cut into launches whose heaps and visited tables together stay below about 2 GiB.
+        const char* ce = getenv("VDB_LITERAL_CAND_CAP");                  // tests: a queue that is too small is an error, never a wrong answer
+        size_t cap = ids.size() + 1;
+        if (ce && atoi(ce) > 0) cap = std::min<size_t>(cap, (size_t)atoi(ce));
+        a.cand_cap = (uint32_t)cap;
+        size_t table_bytes = size_t(4) << 15;
+        while (table_bytes < (size_t(4) << 30) && table_bytes * 3 / 16 < ids.size() + 4 * WAVE_LANES) table_bytes <<= 1;
+        const size_t per_query = cap * sizeof(vdb_scored_point) + table_bytes;
+        const size_t chunk = std::max<size_t>(1, std::min<size_t>(nq, (size_t(2) << 30) / per_query));
+        s_cand.reserve(chunk * cap, stream, false);
         a.cand_scratch = s_cand.p;
-    }
+        for (size_t q0 = 0; q0 < nq; q0 += chunk) {
+            SearchArgs b = a;
+            b.nq = (uint32_t)std::min(chunk, nq - q0);
+            b.queries = a.queries + q0 * dim; b.out = a.out + q0 * top_k; b.out_n = a.out_n + q0; b.stats = a.stats + q0;
+            run_search(b, b.nq, stream, true, b.queries);
+        }
+    } else
     run_search(a, nq, stream, true, s_q.p);
     std::vector<vdb_query_stats> st(nq);
     if (small) {

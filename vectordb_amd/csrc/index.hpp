@@ -101,7 +101,7 @@ struct vdb_index {
     mutable void* h_pin = nullptr; mutable size_t h_pin_bytes = 0;     // pinned staging of small search batches (one query per call is the reference's shape)
     void* pinned(size_t bytes) const;
     mutable vdb::DevBuf<float> s_q, s_raw; mutable vdb::DevBuf<vdb_scored_point> s_out, s_cand;
-    mutable vdb::DevBuf<uint32_t> s_n, s_slots, s_qslots, s_lvl, s_off, s_nb, s_nbc, s_bin, s_bout, s_hash, s_spill; mutable vdb::DevBuf<vdb_query_stats> s_stats;
+    mutable vdb::DevBuf<uint32_t> s_n, s_slots, s_qslots, s_lvl, s_off, s_nb, s_nbc, s_bin, s_bout, s_hash, s_spill, s_spill_lit; mutable vdb::DevBuf<vdb_query_stats> s_stats;
     mutable std::map<hipStream_t, vdb::DevBuf<vdb_query_stats>> s_stats_by_stream;
     // exact k-NN scratch per stream: device-buffer calls return before their kernels have run, so calls on different
     // streams must not share it

@@ -22,6 +22,7 @@ constexpr int MT = 32;             // base rows per tile (the M side)
 // lane of the compacting wave.
 template <int KP> struct KnnBuf { static constexpr int CAP = KP == 16 ? 40 : 64, TRIG = CAP - 16; };
 constexpr float INF_F = __builtin_inff();
+constexpr int knn_tile_buffers(int kh) { return kh <= 64 ? 2 : 1; }
 
 // Keeps the KP smallest entries of query `qi`'s candidate buffer, ordered by (ranking key, PointId) — the order of
 // the final result, so rows that tie exactly (repeated vectors) survive by id whatever their slots are.  All lanes of
@@ -86,11 +87,14 @@ __global__ void __launch_bounds__(256) knn_mfma_kernel(GraphView gv, const float
     constexpr int K = 2 * KH, LDA = K + 4;                     // padded tile row: conflict-free 16-byte reads
     constexpr int KNN_CAP = KnnBuf<KNN_KP>::CAP, KNN_TRIG = KnnBuf<KNN_KP>::TRIG;
     constexpr int VPT = K / 32;                                // float4 per thread per tile (256 threads, 32 rows)
+    // Two tile buffers where they fit beside the candidate buffers of two blocks per CU (rows up to 128 floats): the next
+    // tile is written while this one is contracted and one block barrier per tile is enough; one buffer otherwise.
+    constexpr int NBUF = knn_tile_buffers(KH);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* At = reinterpret_cast<float*>(smem);                                  // MT x LDA
-    float* sc_t = At + MT * LDA;                                                 // MT
-    float* bi_t = sc_t + MT;                                                     // MT
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(bi_t + MT);                      // MQ
+    float* At = reinterpret_cast<float*>(smem);                                  // NBUF x MT x LDA
+    float* sc_t = At + NBUF * MT * LDA;                                          // NBUF x MT
+    float* bi_t = sc_t + NBUF * MT;                                              // NBUF x MT
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(bi_t + NBUF * MT);               // MQ
     uint2* buf = reinterpret_cast<uint2*>(cnt + MQ);                             // MQ x KNN_CAP {key bits, row}
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -127,23 +131,35 @@ __global__ void __launch_bounds__(256) knn_mfma_kernel(GraphView gv, const float
         }
         if (tid < MT) { const uint32_t rr = tile_base + tid; st_sc = rr < r_end ? scale[rr] : 0.f; st_bi = rr < r_end ? bias[rr] : INF_F; }
     };
-    auto stash = [&]() {
+    auto stash = [&](uint32_t ib) {
 #pragma unroll
-        for (int v = 0; v < VPT; ++v) *reinterpret_cast<float4*>(At + lrow * LDA + lpart * (K / 8) + v * 4) = stage[v];
-        if (tid < MT) { sc_t[tid] = st_sc; bi_t[tid] = st_bi; }
+        for (int v = 0; v < VPT; ++v) *reinterpret_cast<float4*>(At + ib * (MT * LDA) + lrow * LDA + lpart * (K / 8) + v * 4) = stage[v];
+        if (tid < MT) { sc_t[ib * MT + tid] = st_sc; bi_t[ib * MT + tid] = st_bi; }
     };
 
 
     if (r_begin < r_end) fetch(r_begin);
-    for (uint32_t tb = r_begin; tb < r_end; tb += MT) {
-        __syncthreads();                           // the previous tile has been consumed
-        stash();
+    if (NBUF == 2) {
+        if (r_begin < r_end) stash(0);
         __syncthreads();
-        if (tb + MT < r_end) fetch(tb + MT);       // in flight during the contraction
+        if (r_begin + MT < r_end) fetch(r_begin + MT);
+    }
+    uint32_t ib = 0;
+    for (uint32_t tb = r_begin; tb < r_end; tb += MT) {
+        if (NBUF == 1) {
+            __syncthreads();                           // the previous tile has been consumed
+            stash(0);
+            __syncthreads();
+            if (tb + MT < r_end) fetch(tb + MT);       // in flight during the contraction
+        } else {
+            // the other buffer was last read during the previous tile, which every wave left through the barrier below
+            if (tb + MT < r_end) stash(ib ^ 1u);
+            if (tb + 2 * MT < r_end) fetch(tb + 2 * MT);
+        }
         floatx16 acc;
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[v] = 0.f;
-        const float* arow = At + j * LDA + h * KH;
+        const float* arow = At + ib * (MT * LDA) + j * LDA + h * KH;
         float4 afrag[KH / 4];                     // the lane's whole slice of the tile: reads run ahead of the MFMAs
 #pragma unroll
         for (int c = 0; c < KH / 4; ++c) afrag[c] = *reinterpret_cast<const float4*>(arow + 4 * c);
@@ -159,8 +175,8 @@ __global__ void __launch_bounds__(256) knn_mfma_kernel(GraphView gv, const float
         float key[16];
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            const float4 s4 = *reinterpret_cast<const float4*>(sc_t + g4 * 8 + h * 4);
-            const float4 b4 = *reinterpret_cast<const float4*>(bi_t + g4 * 8 + h * 4);
+            const float4 s4 = *reinterpret_cast<const float4*>(sc_t + ib * MT + g4 * 8 + h * 4);
+            const float4 b4 = *reinterpret_cast<const float4*>(bi_t + ib * MT + g4 * 8 + h * 4);
             key[g4 * 4 + 0] = __builtin_fmaf(acc[g4 * 4 + 0], s4.x, b4.x);
             key[g4 * 4 + 1] = __builtin_fmaf(acc[g4 * 4 + 1], s4.y, b4.y);
             key[g4 * 4 + 2] = __builtin_fmaf(acc[g4 * 4 + 2], s4.z, b4.z);
@@ -194,6 +210,7 @@ __global__ void __launch_bounds__(256) knn_mfma_kernel(GraphView gv, const float
                 }
             }
         }
+        if (NBUF == 2) { __syncthreads(); ib ^= 1u; }  // this tile is consumed, the next one is complete
     }
     // hand over: KNN_KP slots per (query, chunk), NONE32 marks unused entries
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -449,7 +466,7 @@ uint32_t resident_blocks(Kernel kernel, size_t lds) {
 template <int KH, int KP>
 uint32_t launch_mfma(const GraphView& g, const float* queries, uint32_t nq, const float* scale, const float* bias, uint32_t* slots, uint32_t max_chunks, hipStream_t st) {
     constexpr int K = 2 * KH;
-    const size_t lds = (size_t)MT * (K + 4) * 4 + 2 * MT * 4 + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8;
+    const size_t lds = (size_t)knn_tile_buffers(KH) * ((size_t)MT * (K + 4) * 4 + 2 * MT * 4) + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8;
     const uint32_t n_chunks = pick_chunks(g.n, nq, resident_blocks(knn_mfma_kernel<KH, KP>, lds), max_chunks);
     hipLaunchKernelGGL((knn_mfma_kernel<KH, KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, queries, nq, scale, bias, slots, n_chunks);
     return n_chunks;

@@ -684,9 +684,42 @@ struct Searcher {
         wave_sync();
     }
 
-    // hnsw.rs:585-689 as written.  C is an unsorted array in global scratch; R (inverted order in
-    // the reference) keeps the ef LARGEST keys among entry + passing nodes and `bound` is its
-    // smallest key; output is descending by key.
+    // Candidate queue of the literal filtered walk: std::collections::BinaryHeap<ScoredPoint> (hnsw.rs:638) in this
+    // query's slice of HBM scratch, restated operation by operation so that equal keys leave it in the reference's
+    // order.  ScoredPoint's Ord is inverted (hnsw.rs:25-39): a <= b in heap terms means a.sort_key >= b.sort_key, the
+    // smallest key sits at the top.  One lane runs the dependent chain of loads; the slice belongs to this wavefront.
+    static __device__ __forceinline__ void heap_sift_up(vdb_scored_point* C, uint32_t pos, const vdb_scored_point elt) {
+        while (pos > 0) {                                                  // BinaryHeap::sift_up(0, pos)
+            const uint32_t parent = (pos - 1) / 2;
+            const vdb_scored_point pe = C[parent];
+            if (elt.sort_key >= pe.sort_key) break;                        // hole.element() <= hole.get(parent)
+            C[pos] = pe; pos = parent;
+        }
+        C[pos] = elt;
+    }
+    static __device__ __forceinline__ void heap_push(vdb_scored_point* C, uint32_t len, const vdb_scored_point elt) { heap_sift_up(C, len, elt); }
+    // BinaryHeap::pop: the last element takes the root's place, sinks to the bottom along the smaller-key children
+    // (equal keys: the right child) and rises again (sift_down_to_bottom + sift_up).  len = entries before the pop.
+    static __device__ __forceinline__ vdb_scored_point heap_pop(vdb_scored_point* C, uint32_t len) {
+        const vdb_scored_point last = C[len - 1];
+        const uint32_t end = len - 1;
+        if (end == 0) return last;
+        const vdb_scored_point top = C[0];
+        uint32_t pos = 0, child = 1;
+        const uint32_t lim = end >= 2 ? end - 2 : 0;
+        while (child <= lim) {
+            vdb_scored_point ce = C[child];
+            const vdb_scored_point re = C[child + 1];
+            if (ce.sort_key >= re.sort_key) { ++child; ce = re; }          // hole.get(child) <= hole.get(child + 1)
+            C[pos] = ce; pos = child; child = 2 * pos + 1;
+        }
+        if (child == end - 1) { C[pos] = C[child]; pos = child; }
+        heap_sift_up(C, pos, last);
+        return top;
+    }
+
+    // hnsw.rs:585-689 as written.  C is the candidate heap above; R (inverted order in the reference) keeps the ef
+    // LARGEST keys among entry + passing nodes and `bound` is its smallest key; output is descending by key.
     __device__ __forceinline__ void literal_filtered(uint32_t q, uint32_t entry) {
         const int lane = lane_id();
         vdb_scored_point* C = a.cand_scratch + (size_t)q * a.cand_cap;
@@ -696,31 +729,18 @@ struct Searcher {
         wave_sync();
         const float raw0 = score_one(entry);
         const float key0 = key_of(raw0);
-        if (lane == 0) { C[0].id = entry; C[0].raw_score = raw0; C[0].sort_key = key0; vis.insert(entry); }
+        if (lane == 0) { vdb_scored_point e; e.id = entry; e.raw_score = raw0; e.sort_key = key0; heap_push(C, 0, e); vis.insert(entry); }
         cn = 1; note_visited(1);
         R.insert(-key0, entry);                                            // hnsw.rs:641-644: entry admitted unfiltered
         float bound = key0;                                                // hnsw.rs:646
-        __threadfence_block();
         wave_sync();
         for (;;) {
             if (cn == 0) break;
-            // pop the minimum of C (hnsw.rs:648); ties: lowest position
-            float bk = 0.f; uint32_t bi = NONE32;
-            for (uint32_t b = 0; b < cn; b += WAVE) {
-                const uint32_t i = b + lane;
-                if (i < cn) { float k = C[i].sort_key; if (bi == NONE32 || k < bk) { bk = k; bi = i; } }
-            }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const float ok_ = __shfl_xor(bk, off); const uint32_t oi = (uint32_t)__shfl_xor((int)bi, off);
-                if (oi != NONE32 && (bi == NONE32 || ok_ < bk || (ok_ == bk && oi < bi))) { bk = ok_; bi = oi; }
-            }
-            const uint32_t cur = (uint32_t)C[bi].id;
-            wave_sync();
-            if (lane == 0) C[bi] = C[cn - 1];
+            // pop the minimum of C (hnsw.rs:648)
+            uint32_t cur = 0; float bk = 0.f;
+            if (lane == 0) { const vdb_scored_point t = heap_pop(C, cn); cur = (uint32_t)t.id; bk = t.sort_key; }
+            cur = readlane_u(cur, 0); bk = readlane_f(bk, 0);
             --cn;
-            __threadfence_block();
-            wave_sync();
             if (bk > bound) break;                                         // hnsw.rs:649-651
             const Adj A = open_adj(gv, 0, cur);
             if (A.deg == 0) continue;
@@ -742,7 +762,9 @@ struct Searcher {
                 const float rj = (lane < m) ? craw[lane] : 0.f;
                 const float kj = key_of(rj);
                 const uint32_t sj = (lane < m) ? cand[lane] : 0u;
-                if (lane < m) { C[cn + lane].id = sj; C[cn + lane].raw_score = rj; C[cn + lane].sort_key = kj; }   // hnsw.rs:666
+                if (lane == 0) {                                           // hnsw.rs:666: every scored neighbour, in list order
+                    for (int j = 0; j < m; ++j) { vdb_scored_point e; e.id = cand[j]; e.raw_score = craw[j]; e.sort_key = key_of(craw[j]); heap_push(C, cn + j, e); }
+                }
                 cn += m;
                 uint64_t pm = ballot(lane < m && a.pass_bits && bit_test(a.pass_bits, sj));
                 if (!a.pass_bits) pm = ballot(lane < m);
@@ -758,7 +780,6 @@ struct Searcher {
                     R.insert(-k, readlane_u(sj, j));
                     bound = -R.key[R.n - 1];                                // peek(): smallest key kept
                 }
-                __threadfence_block();
                 wave_sync();
                 if (!visited_room()) return;
             }

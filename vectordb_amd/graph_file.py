@@ -52,20 +52,76 @@ def write_graph(path, g, *, metric, m, ef, max_level_cap, seed=0, level_draws=0,
 def read_graph(path):
     """-> (config dict, graph dict as import_graph takes it)."""
     with open(path, "rb") as f:
-        raw = f.read(_HEADER.size)
-        if len(raw) != _HEADER.size:
-            raise ValueError("graph file is truncated")
-        (magic, version, metric, m, ef, cap, dim, n, n_layers, has_entry, entry, cur_max, level_draws, sample_draws,
-         seed) = _HEADER.unpack(raw)
-        if magic != MAGIC or version != 1:
-            raise ValueError("not a version-1 graph file")
-        ids = _get(f, n, np.uint64); levels = _get(f, n, np.uint32); deleted = _get(f, n, np.uint8)
-        vectors = _get(f, n * dim, np.float32).reshape(n, dim)
-        layers = []
-        for _ in range(n_layers):
-            n_lists, n_edges = struct.unpack("<QQ", f.read(16))
-            layers.append((_get(f, n_lists, np.uint32), _get(f, n_lists + 1, np.uint64), _get(f, n_edges, np.uint32)))
+        return _read_graph(f)
+
+
+def _read_graph(f):
+    raw = f.read(_HEADER.size)
+    if len(raw) != _HEADER.size:
+        raise ValueError("graph file is truncated")
+    (magic, version, metric, m, ef, cap, dim, n, n_layers, has_entry, entry, cur_max, level_draws, sample_draws,
+     seed) = _HEADER.unpack(raw)
+    if magic != MAGIC or version != 1:
+        raise ValueError("not a version-1 graph file")
+    ids = _get(f, n, np.uint64); levels = _get(f, n, np.uint32); deleted = _get(f, n, np.uint8)
+    vectors = _get(f, n * dim, np.float32).reshape(n, dim)
+    layers = []
+    for _ in range(n_layers):
+        n_lists, n_edges = struct.unpack("<QQ", f.read(16))
+        layers.append((_get(f, n_lists, np.uint32), _get(f, n_lists + 1, np.uint64), _get(f, n_edges, np.uint32)))
     cfg = dict(metric=metric, m=m, ef=ef, max_level_cap=cap, dim=dim, seed=seed, level_draws=level_draws, sample_draws=sample_draws)
     g = dict(ids=ids, levels=levels, vectors=vectors, deleted=deleted, layers=layers,
              entry=entry if has_entry else None, current_max_level=cur_max)
     return cfg, g
+
+
+SEGMENT_MAGIC = b"VDBSEGM1"
+_KINDS = ("Int", "Float", "Str", "Bool", "ListInt", "ListFloat", "ListStr", "ListBool")
+
+
+def _u64(f):
+    raw = f.read(8)
+    if len(raw) != 8:
+        raise ValueError("segment file is truncated")
+    return struct.unpack("<Q", raw)[0]
+
+
+def _string(f):
+    n = _u64(f)
+    raw = f.read(n)
+    if len(raw) != n:
+        raise ValueError("segment file is truncated")
+    if n % 8:
+        f.read(8 - n % 8)
+    return raw.decode("utf-8")
+
+
+def _value(f):
+    kind = _u64(f)
+    if kind == 0: return ("Int", struct.unpack("<q", f.read(8))[0])
+    if kind == 1: return ("Float", struct.unpack("<d", f.read(8))[0])
+    if kind == 2: return ("Str", _string(f))
+    if kind == 3: return ("Bool", _u64(f) != 0)
+    if kind == 4: return ("ListInt", _get(f, _u64(f), np.int64).tolist())
+    if kind == 5: return ("ListFloat", _get(f, _u64(f), np.float64).tolist())
+    if kind == 6: return ("ListStr", [_string(f) for _ in range(_u64(f))])
+    if kind == 7: return ("ListBool", [bool(b) for b in _get(f, _u64(f), np.uint8)])
+    raise ValueError(f"unknown payload value kind {kind}")
+
+
+def read_segment(path):
+    """A file written by `vdb_segment_save` -> (config, graph, dict(next_id, deleted=[ids], payloads={id: {key: (kind, value)}}))."""
+    with open(path, "rb") as f:
+        cfg, g = _read_graph(f)
+        if f.read(8) != SEGMENT_MAGIC:
+            raise ValueError("the file holds an index but no segment section")
+        next_id, n_del, n_pay = _u64(f), _u64(f), _u64(f)
+        deleted = [_u64(f) for _ in range(n_del)]
+        payloads = {}
+        for _ in range(n_pay):
+            pid, nf = _u64(f), _u64(f)
+            payloads[pid] = {}
+            for _ in range(nf):
+                key = _string(f)
+                payloads[pid][key] = _value(f)
+    return cfg, g, dict(next_id=next_id, deleted=deleted, payloads=payloads)
