@@ -209,7 +209,9 @@ vdb_status vdb_index_search(const vdb_index* x, const float* q, size_t len, size
 vdb_status vdb_index_search_batch(const vdb_index* x, const float* queries, size_t nq, size_t len, size_t top_k,
                                   size_t ef_search, vdb_scored_point* out, uint32_t* out_n, vdb_query_stats* stats);
 /* Same with queries and results resident in device memory, enqueued on `stream` (hipStream_t,
- * NULL = the index's own stream) without a host synchronisation.  d_stats may be NULL. */
+ * NULL = the index's own stream) without a host synchronisation.  d_stats may be NULL; pass it when
+ * ef_search exceeds 256: only that path can run out of visited-table space, which it reports as
+ * flags & 1 in d_stats with out_n = 0 for the query (the host-buffer call repeats such a query by itself). */
 vdb_status vdb_index_search_batch_dev(const vdb_index* x, const float* d_queries, size_t nq, size_t top_k,
                                       size_t ef_search, vdb_scored_point* d_out, uint32_t* d_out_n,
                                       vdb_query_stats* d_stats, void* stream);

@@ -1,0 +1,89 @@
+//! Raw bindings of include/vdbmi.h (the subset the wrappers call; `bindgen include/vdbmi.h` produces all of it).
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_double, c_int, c_void};
+
+#[repr(C)] pub struct vdb_index { _p: [u8; 0] }
+#[repr(C)] pub struct vdb_segment { _p: [u8; 0] }
+#[repr(C)] pub struct vdb_value { _p: [u8; 0] }
+#[repr(C)] pub struct vdb_payload { _p: [u8; 0] }
+#[repr(C)] pub struct vdb_filter { _p: [u8; 0] }
+
+/// ScoredPoint, src/vector/hnsw.rs:11-16
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct vdb_scored_point { pub id: u64, pub raw_score: f32, pub sort_key: f32 }
+
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct vdb_options { pub seed: u64, pub device: i32, pub arith: i32, pub filter_mode: i32, pub beam_width: i32 }
+
+pub const VDB_OK: c_int = 0;
+pub const VDB_ERR_NOT_FOUND: c_int = 1;
+pub const VDB_ERR_VECTOR_LENGTH_MISMATCH: c_int = 2;
+pub const VDB_ERR_IO: c_int = 3;
+pub const VDB_ERR_INVALID_PAYLOAD: c_int = 6;
+pub const VDB_ERR_SEARCH: c_int = 7;
+pub const VDB_ERR_PANIC: c_int = 99;
+
+extern "C" {
+    pub fn vdb_last_error_message() -> *const c_char;
+    pub fn vdb_default_options(out: *mut vdb_options);
+    pub fn vdb_score(a: *const f32, na: usize, b: *const f32, nb: usize, metric: c_int, out: *mut f32) -> c_int;
+
+    pub fn vdb_value_int(v: i64) -> *mut vdb_value;
+    pub fn vdb_value_float(v: c_double) -> *mut vdb_value;
+    pub fn vdb_value_str(s: *const c_char, len: usize) -> *mut vdb_value;
+    pub fn vdb_value_bool(v: c_int) -> *mut vdb_value;
+    pub fn vdb_value_list_int(v: *const i64, n: usize) -> *mut vdb_value;
+    pub fn vdb_value_list_float(v: *const c_double, n: usize) -> *mut vdb_value;
+    pub fn vdb_value_list_str(s: *const *const c_char, lens: *const usize, n: usize) -> *mut vdb_value;
+    pub fn vdb_value_list_bool(v: *const u8, n: usize) -> *mut vdb_value;
+    pub fn vdb_value_free(v: *mut vdb_value);
+    pub fn vdb_payload_new() -> *mut vdb_payload;
+    pub fn vdb_payload_free(p: *mut vdb_payload);
+    pub fn vdb_payload_set(p: *mut vdb_payload, key: *const c_char, v: *const vdb_value) -> c_int;
+    pub fn vdb_filter_match(key: *const c_char, v: *const vdb_value) -> *mut vdb_filter;
+    pub fn vdb_filter_compare(key: *const c_char, op: c_int, v: *const vdb_value) -> *mut vdb_filter;
+    pub fn vdb_filter_and(children: *const *const vdb_filter, n: usize) -> *mut vdb_filter;
+    pub fn vdb_filter_or(children: *const *const vdb_filter, n: usize) -> *mut vdb_filter;
+    pub fn vdb_filter_not(child: *const vdb_filter) -> *mut vdb_filter;
+    pub fn vdb_filter_free(f: *mut vdb_filter);
+
+    pub fn vdb_index_new(metric: c_int, m: usize, ef: usize, max_level_cap: usize, dim: usize, opts: *const vdb_options, out: *mut *mut vdb_index) -> c_int;
+    pub fn vdb_index_free(x: *mut vdb_index);
+    pub fn vdb_index_insert(x: *mut vdb_index, id: u64, v: *const f32, len: usize) -> c_int;
+    pub fn vdb_index_insert_batch(x: *mut vdb_index, ids: *const u64, v: *const f32, n: usize, len: usize) -> c_int;
+    pub fn vdb_index_search(x: *const vdb_index, q: *const f32, len: usize, top_k: usize, out: *mut vdb_scored_point, out_n: *mut usize) -> c_int;
+    pub fn vdb_index_search_batch(x: *const vdb_index, q: *const f32, nq: usize, len: usize, top_k: usize, ef_search: usize,
+                                  out: *mut vdb_scored_point, out_n: *mut u32, stats: *mut c_void) -> c_int;
+    pub fn vdb_index_mark_deleted(x: *mut vdb_index, id: u64) -> c_int;
+    pub fn vdb_index_contains(x: *const vdb_index, id: u64) -> c_int;
+    pub fn vdb_index_len(x: *const vdb_index) -> usize;
+    pub fn vdb_index_current_max_level(x: *const vdb_index) -> usize;
+    pub fn vdb_index_get_entry_point(x: *const vdb_index, out: *mut u64) -> c_int;
+    pub fn vdb_index_set_entry_point(x: *mut vdb_index, id: u64) -> c_int;
+    pub fn vdb_index_set_current_max_level(x: *mut vdb_index, level: usize) -> c_int;
+    pub fn vdb_index_get_vector(x: *const vdb_index, id: u64, out: *mut f32, cap: usize) -> c_int;
+    pub fn vdb_index_layer_neighbors(x: *const vdb_index, level: usize, id: u64, out: *mut u64, cap: usize, out_n: *mut usize, is_some: *mut c_int) -> c_int;
+    pub fn vdb_index_maybe_normalize(x: *const vdb_index, v: *const f32, len: usize, out: *mut f32) -> c_int;
+    pub fn vdb_index_add_bidirectional_edge(x: *mut vdb_index, level: usize, a: u64, b: u64) -> c_int;
+    pub fn vdb_index_greedy_search_layer_unfiltered(x: *const vdb_index, q: *const f32, len: usize, entry: u64, level: usize, out_id: *mut u64) -> c_int;
+
+    pub fn vdb_segment_new(hnsw: *mut vdb_index, out: *mut *mut vdb_segment) -> c_int;
+    pub fn vdb_segment_free(s: *mut vdb_segment);
+    pub fn vdb_segment_insert(s: *mut vdb_segment, v: *const f32, len: usize, payload: *const vdb_payload, out_id: *mut u64) -> c_int;
+    pub fn vdb_segment_delete(s: *mut vdb_segment, id: u64) -> c_int;
+    pub fn vdb_segment_purge(s: *mut vdb_segment) -> c_int;
+    pub fn vdb_segment_is_deleted(s: *const vdb_segment, id: u64) -> c_int;
+    pub fn vdb_segment_hnsw_mut(s: *mut vdb_segment) -> *mut vdb_index;
+    pub fn vdb_segment_search(s: *const vdb_segment, q: *const f32, len: usize, top_k: usize, out: *mut vdb_scored_point, out_n: *mut usize) -> c_int;
+    pub fn vdb_segment_search_with_filter(s: *const vdb_segment, q: *const f32, len: usize, top_k: usize, f: *const vdb_filter,
+                                          out: *mut vdb_scored_point, out_n: *mut usize) -> c_int;
+    pub fn vdb_segment_search_unfiltered(s: *const vdb_segment, q: *const f32, len: usize, top_k: usize, out: *mut vdb_scored_point, out_n: *mut usize) -> c_int;
+    pub fn vdb_segment_post_filter(s: *const vdb_segment, q: *const f32, len: usize, top_k: usize, f: *const vdb_filter,
+                                   out: *mut vdb_scored_point, out_n: *mut usize) -> c_int;
+    pub fn vdb_segment_in_place_filtered_search(s: *const vdb_segment, q: *const f32, len: usize, top_k: usize, f: *const vdb_filter,
+                                                out: *mut vdb_scored_point, out_n: *mut usize) -> c_int;
+    pub fn vdb_segment_search_batch(s: *const vdb_segment, q: *const f32, nq: usize, len: usize, top_k: usize, ef_search: usize, f: *const vdb_filter,
+                                    out: *mut vdb_scored_point, out_n: *mut u32) -> c_int;
+    pub fn vdb_segment_save(s: *const vdb_segment, path: *const c_char) -> c_int;
+    pub fn vdb_segment_load(s: *mut vdb_segment, path: *const c_char) -> c_int;
+}

@@ -179,7 +179,7 @@ def test_a_saved_and_loaded_segment_answers_and_grows_like_the_original(ora, vdb
     # the file as the Python reader sees it
     cfg, g, seg = graph_file.read_segment(path)
     assert seg["next_id"] == n + 1 and seg["deleted"] == [4, 51, 52, 201] and len(seg["payloads"]) == sv.payload_count()
-    assert seg["payloads"][1]["cat"] == ("Int", 0) and seg["payloads"][26]["nums"] == ("ListInt", [25, -25]) and seg["payloads"][10]["name"] == ("Str", "ccc é")
+    assert seg["payloads"][2]["cat"] == ("Int", 1) and 1 not in seg["payloads"] and seg["payloads"][26]["nums"] == ("ListInt", [25, -25]) and seg["payloads"][16]["name"] == ("Str", "ccc é")
     assert cfg["dim"] == d and len(g["ids"]) == n
     # loaded into a segment created with another seed: everything comes from the file
     sl = fresh(vdb, seed=99, arith=vdb.Arith.Strict)

@@ -562,8 +562,9 @@ void vdb_index::run_search(SearchArgs a, size_t nq, hipStream_t s, bool retry_on
     a.spill_locks = s_spill.p; a.spill_pool = s_spill.p + a.spill_tables;
     }
     launch_search(a, s);
-    // the register-resident beam never overflows (its visited set forgets instead): nothing to follow up
-    if (reg_list_chunks(a) > 0) return;
+    // the register-resident beam never overflows (its visited set forgets instead): nothing to follow up — except during
+    // construction, whose upper-layer beams keep the exact visited table and would leave a point unlinked on overflow
+    if (reg_list_chunks(a) > 0 && a.mode != MODE_BUILD) return;
     if (!retry_on_overflow) return;
     std::vector<vdb_query_stats> st(nq);
     VDB_HIP(hipMemcpyAsync(st.data(), a.stats, nq * sizeof(vdb_query_stats), hipMemcpyDeviceToHost, s));
