@@ -1,6 +1,7 @@
 // gfx950 (MI355X) kernels of libvdbmi other than the graph search: the streaming distance scan, row
 // normalisation, the exact k-NN and the k-way merge; plus the dispatcher of the search launchers.
 // Compiled with -ffp-contract=off (see device_common.hpp).
+#include <type_traits>
 #include "device_common.hpp"
 
 #include <algorithm>
@@ -64,68 +65,195 @@ __global__ void __launch_bounds__(256) scan_strict_kernel(const float* __restric
     }
 }
 
-template <int G, int CH>
+// Shape of the FAST scan, from measurements on 1M x 768 / 960 rows against 8 queries: two rows per lane group and
+// step (one row doubles the LDS reads and is 8 % slower), one step of rows in flight (two or three are no faster:
+// with eight queries the kernel is bound by LDS reads and issue, not by bytes in flight), all queries of the block in
+// one pass over the rows' registers.
+constexpr int SCAN_QH = 8, SCAN_QB = 1, SCAN_NB = 2;
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
+// V partial sums per lane, to be summed over W adjacent lanes.  While more than one value is left a step halves the
+// values instead of repeating the exchange: the lane whose bit W/2 is set keeps the upper half and hands the lower half to
+// its partner, so V values cost about V exchanges instead of V log2(W).  Afterwards, with g the lane's position among
+// the G lanes the first call was made for: V >= G leaves a[0 .. V/G) = totals of values g * (V/G) + i; V < G leaves
+// a[0] = total of value g / (G/V) in every lane of that run.
+template <int V, int W>
+__device__ __forceinline__ void fold_lanes(float* a, int g) {
+    if constexpr (W > 1) {
+        constexpr int M = W / 2;
+        if constexpr (V > 1) {
+            const bool up = (g & M) != 0;
+#pragma unroll
+            for (int i = 0; i < V / 2; ++i) {
+                const float send = up ? a[i] : a[i + V / 2];
+                const float keep = up ? a[i + V / 2] : a[i];
+                a[i] = keep + __shfl_xor(send, M, WAVE);
+            }
+            fold_lanes<V / 2, M>(a, g);
+        } else {
+            a[0] += __shfl_xor(a[0], M, WAVE);
+            fold_lanes<1, M>(a, g);
+        }
+    }
+}
+
+// FAST scan.  G lanes share a row (CH float4 each), a wave step covers R rows per group = R * 64 / G rows, and the rows
+// of the next step are in flight while this one is scored against the QT queries of the block (read from LDS once per
+// R rows).  Sums run as packed pairs (v_pk_fma_f32) and are folded across the group by fold_lanes.
+template <int G, int CH, int R, int QT, int NB>
 __global__ void __launch_bounds__(256) scan_fast_kernel(const float* __restrict__ queries, uint32_t nq, const float* __restrict__ base,
                                                        uint32_t n, uint32_t dim, uint32_t stride, int metric, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* q = reinterpret_cast<float*>(smem);
     const uint32_t qpad = (dim + 3u) & ~3u;
     const uint32_t q0 = blockIdx.y * SCAN_Q;
-    const uint32_t qn = min((uint32_t)SCAN_Q, nq - q0);
-    for (uint32_t i = threadIdx.x; i < SCAN_Q * qpad; i += blockDim.x) {
-        const uint32_t t = i / qpad, d = i % qpad;
+    const uint32_t qn = min((uint32_t)QT, nq - q0);
+    constexpr int QS = G * CH;                                 // float4 per query in LDS: one per (lane of the group, step), zero beyond the row
+    for (uint32_t i = threadIdx.x; i < QT * QS * 4; i += blockDim.x) {
+        const uint32_t t = i / (QS * 4), d = i % (QS * 4);
         q[i] = (t < qn && d < dim) ? queries[(size_t)(q0 + t) * dim + d] : 0.f;
     }
     __syncthreads();
-    constexpr int RPP = WAVE / G;
+    constexpr int RPW = (WAVE / G) * R;                        // rows per wave step
+    constexpr int QH = QT < SCAN_QH ? QT : SCAN_QH;                        // queries scored per pass over the registers holding the rows
+    constexpr int V = QH * R;                                  // partial sums per lane and pass
     const int lane = lane_id(), g = lane % G, rr = lane / G;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE, nwaves = gridDim.x * blockDim.x / WAVE;
     const uint32_t nchunks = qpad >> 2;
-    float qn2[SCAN_Q];
+    const float4* q4 = reinterpret_cast<const float4*>(q);
+    float qn2[QT];
     if (metric == VDB_COSINE) {
 #pragma unroll
-        for (int t = 0; t < SCAN_Q; ++t) {
+        for (int t = 0; t < QT; ++t) {
             float acc = 0.f;
             for (int j = 0; j < CH; ++j) {
                 const uint32_t c = g + G * j;
-                if (c < nchunks) { const float4 v = reinterpret_cast<const float4*>(q + t * qpad)[c];
-                    acc = __builtin_fmaf(v.x, v.x, acc); acc = __builtin_fmaf(v.y, v.y, acc); acc = __builtin_fmaf(v.z, v.z, acc); acc = __builtin_fmaf(v.w, v.w, acc); }
+                const float4 v = q4[t * QS + c];
+                acc = __builtin_fmaf(v.x, v.x, acc); acc = __builtin_fmaf(v.y, v.y, acc); acc = __builtin_fmaf(v.z, v.z, acc); acc = __builtin_fmaf(v.w, v.w, acc);
             }
             qn2[t] = __builtin_sqrtf(group_sum<G>(acc));
         }
     }
-    for (uint32_t r0 = wave * RPP; r0 < n; r0 += nwaves * RPP) {
-        const uint32_t r = r0 + rr;
-        const bool live = r < n;
-        float4 x[CH];
-        const float4* row = reinterpret_cast<const float4*>(base + (size_t)(live ? r : 0) * stride);
+    constexpr int VO = V >= G ? V / G : 1;                     // totals a lane holds after the fold
+    constexpr int RUN = V >= G ? 1 : G / V;                    // lanes that end up with the same total
+    const bool writer = g % RUN == 0;
+    uint32_t my_t[VO], my_i[VO];              // which (query, row of the step) each total belongs to
 #pragma unroll
-        for (int j = 0; j < CH; ++j) { const uint32_t c = g + G * j; x[j] = (live && c < nchunks) ? row[c] : make_float4(0.f, 0.f, 0.f, 0.f); }
-        float xb = 0.f;
+    for (int o = 0; o < VO; ++o) {
+        const uint32_t idx = V >= G ? (uint32_t)g * VO + o : (uint32_t)g / RUN;
+        my_t[o] = idx / R; my_i[o] = idx % R;                  // query within the pass
+    }
+    auto fetch = [&](float4 (&dst)[R][CH], uint32_t r0) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const uint32_t r = min(r0 + rr * R + i, n - 1);   // rows past the end repeat the last one and are not written
+            const float4* row = reinterpret_cast<const float4*>(base + (size_t)r * stride);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) dst[i][j] = row[min((uint32_t)(g + G * j), nchunks - 1)];   // unconditional: no predicated loads
+        }
+    };
+    auto score = [&](float4 (&x)[R][CH], uint32_t r0) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            if ((uint32_t)(G * (j + 1)) > nchunks) {           // uniform: only the last float4 steps of a row can run past its end
+                const bool past = (uint32_t)(g + G * j) >= nchunks;
+#pragma unroll
+                for (int i = 0; i < R; ++i) if (past) x[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        float xnorm[R];
         if (metric == VDB_COSINE) {
 #pragma unroll
-            for (int j = 0; j < CH; ++j) { xb = __builtin_fmaf(x[j].x, x[j].x, xb); xb = __builtin_fmaf(x[j].y, x[j].y, xb); xb = __builtin_fmaf(x[j].z, x[j].z, xb); xb = __builtin_fmaf(x[j].w, x[j].w, xb); }
-            xb = __builtin_sqrtf(group_sum<G>(xb));
+            for (int i = 0; i < R; ++i) {
+                floatx2 s{0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const floatx2 va{x[i][j].x, x[i][j].y}, vb{x[i][j].z, x[i][j].w};
+                    s = __builtin_elementwise_fma(va, va, s); s = __builtin_elementwise_fma(vb, vb, s);
+                }
+                xnorm[i] = __builtin_sqrtf(group_sum<G>(s.x + s.y));
+            }
         }
 #pragma unroll
-        for (int t = 0; t < SCAN_Q; ++t) {
-            if (t >= (int)qn) break;
-            float acc = 0.f;
+        for (int h = 0; h < QT; h += QH) {
+            floatx2 acc[QH][R];
 #pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                const uint32_t c = g + G * j;
-                const float4 qq = (c < nchunks) ? reinterpret_cast<const float4*>(q + t * qpad)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 v = x[j];
-                if (metric == VDB_EUCLIDEAN) {
-                    float d0 = qq.x - v.x, d1 = qq.y - v.y, d2 = qq.z - v.z, d3 = qq.w - v.w;
-                    acc = __builtin_fmaf(d0, d0, acc); acc = __builtin_fmaf(d1, d1, acc); acc = __builtin_fmaf(d2, d2, acc); acc = __builtin_fmaf(d3, d3, acc);
-                } else {
-                    acc = __builtin_fmaf(qq.x, v.x, acc); acc = __builtin_fmaf(qq.y, v.y, acc); acc = __builtin_fmaf(qq.z, v.z, acc); acc = __builtin_fmaf(qq.w, v.w, acc);
+            for (int t = 0; t < QH; ++t)
+#pragma unroll
+                for (int i = 0; i < R; ++i) acc[t][i] = floatx2{0.f, 0.f};
+            auto accumulate = [&](auto l2) {
+                constexpr int QB = CH <= 4 ? SCAN_QB : 1;            // the next query's slice is read while this one is used (short slices)
+                float4 qq[QB][CH];
+#pragma unroll
+                for (int j = 0; j < CH; ++j) qq[0][j] = q4[h * QS + g + G * j];
+#pragma unroll
+                for (int t = 0; t < QH; ++t) {
+                    if (QB == 2 && t + 1 < QH) {
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) qq[(t + 1) & 1][j] = q4[(h + t + 1) * QS + g + G * j];
+                    }
+                    if (QB == 1 && t > 0) {
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) qq[0][j] = q4[(h + t) * QS + g + G * j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        const float4 qv = qq[QB == 2 ? (t & 1) : 0][j];
+                        const floatx2 qa{qv.x, qv.y}, qb{qv.z, qv.w};
+#pragma unroll
+                        for (int i = 0; i < R; ++i) {
+                            const floatx2 va{x[i][j].x, x[i][j].y}, vb{x[i][j].z, x[i][j].w};
+                            if constexpr (decltype(l2)::value) {
+                                const floatx2 da = qa - va, db = qb - vb;
+                                acc[t][i] = __builtin_elementwise_fma(da, da, acc[t][i]);
+                                acc[t][i] = __builtin_elementwise_fma(db, db, acc[t][i]);
+                            } else {
+                                acc[t][i] = __builtin_elementwise_fma(qa, va, acc[t][i]);
+                                acc[t][i] = __builtin_elementwise_fma(qb, vb, acc[t][i]);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);         // keeps the LDS reads two queries deep: the rows hold the registers
                 }
+            };
+            if (metric == VDB_EUCLIDEAN) accumulate(std::true_type{}); else accumulate(std::false_type{});
+            float a[V];
+#pragma unroll
+            for (int t = 0; t < QH; ++t)
+#pragma unroll
+                for (int i = 0; i < R; ++i) a[t * R + i] = acc[t][i].x + acc[t][i].y;
+            fold_lanes<V, G>(a, g);
+#pragma unroll
+            for (int o = 0; o < VO; ++o) {
+                const uint32_t r = r0 + rr * R + my_i[o], t = h + my_t[o];
+                float raw = a[o];
+                if (metric == VDB_EUCLIDEAN) raw = __builtin_sqrtf(raw);
+                else if (metric == VDB_COSINE) {
+                    float xv = 0.f, qv = 0.f;
+#pragma unroll
+                    for (int ii = 0; ii < R; ++ii) xv = my_i[o] == (uint32_t)ii ? xnorm[ii] : xv;
+#pragma unroll
+                    for (int tt = 0; tt < QH; ++tt) qv = my_t[o] == (uint32_t)tt ? qn2[h + tt] : qv;
+                    raw = 1.0f - raw / (qv * xv + 1e-10f);
+                }
+                if (writer && r < n && t < qn) out[(size_t)(q0 + t) * n + r] = raw;
             }
-            acc = group_sum<G>(acc);
-            float raw = metric == VDB_EUCLIDEAN ? __builtin_sqrtf(acc) : (metric == VDB_DOT ? acc : 1.0f - acc / (qn2[t] * xb + 1e-10f));
-            if (g == 0 && live) out[(size_t)(q0 + t) * n + r] = raw;
+        }
+    };
+    // NB row buffers in turn: the rows of the next NB - 1 steps are in flight while this step is scored (the bytes in
+    // flight per CU, not the arithmetic, set the speed of this kernel)
+    float4 xb[NB][R][CH];
+    const uint32_t step = nwaves * RPW;
+    uint32_t r0 = wave * RPW;
+#pragma unroll
+    for (int b = 0; b < NB - 1; ++b) if (r0 + b * step < n) fetch(xb[b], r0 + b * step);
+    while (true) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (r0 >= n) return;
+            if (r0 + (NB - 1) * step < n) fetch(xb[(b + NB - 1) % NB], r0 + (NB - 1) * step);
+            score(xb[b], r0);
+            r0 += step;
         }
     }
 }
@@ -158,7 +286,7 @@ void launch_score_scan(const float* queries, uint32_t nq, const float* base, uin
                        int metric, int arith, float* out, hipStream_t st) {
     if (nq == 0 || n == 0) return;
     const uint32_t qpad = (dim + 3u) & ~3u;
-    const size_t lds = (size_t)SCAN_Q * qpad * 4;
+    size_t lds = (size_t)SCAN_Q * qpad * 4;
     const uint32_t qblocks = (nq + SCAN_Q - 1) / SCAN_Q;
     const bool aligned = (stride % 4 == 0) && ((uintptr_t)base % 16 == 0);
     if (arith == VDB_ARITH_STRICT || !aligned || qpad / 4 > 512) {
@@ -171,10 +299,13 @@ void launch_score_scan(const float* queries, uint32_t nq, const float* base, uin
     } else {
         const uint32_t chunks = qpad / 4;
         const uint32_t blocks = 256 * 8;
-#define VDB_SCAN(G, CH) hipLaunchKernelGGL((scan_fast_kernel<G, CH>), dim3(blocks, qblocks), dim3(256), lds, st, queries, nq, base, n, dim, stride, metric, out)
-        if (chunks <= 8) VDB_SCAN(8, 1); else if (chunks <= 16) VDB_SCAN(8, 2); else if (chunks <= 24) VDB_SCAN(8, 3);
-        else if (chunks <= 32) VDB_SCAN(8, 4); else if (chunks <= 64) VDB_SCAN(64, 1); else if (chunks <= 128) VDB_SCAN(64, 2);
-        else if (chunks <= 192) VDB_SCAN(64, 3); else if (chunks <= 256) VDB_SCAN(64, 4); else VDB_SCAN(64, 8);
+        const uint32_t qt = nq >= 5 ? 8u : nq >= 3 ? 4u : nq;          // queries a block scores (the last block may hold fewer)
+#define VDB_SCAN_Q(G, CH, R, QT) lds = (size_t)QT * G * CH * 16; hipLaunchKernelGGL((scan_fast_kernel<G, CH, R, QT, SCAN_NB>), dim3(blocks, qblocks), dim3(256), lds, st, queries, nq, base, n, dim, stride, metric, out)
+#define VDB_SCAN(G, CH, R) do { if (qt == 8) { VDB_SCAN_Q(G, CH, R, 8); } else if (qt == 4) { VDB_SCAN_Q(G, CH, R, 4); } else if (qt == 2) { VDB_SCAN_Q(G, CH, R, 2); } else { VDB_SCAN_Q(G, CH, R, 1); } } while (0)
+        if (chunks <= 8) VDB_SCAN(8, 1, 4); else if (chunks <= 16) VDB_SCAN(8, 2, 2); else if (chunks <= 24) VDB_SCAN(8, 3, 2);
+        else if (chunks <= 32) VDB_SCAN(8, 4, 2); else if (chunks <= 64) VDB_SCAN(16, 4, 2); else if (chunks <= 128) VDB_SCAN(32, 4, 2);
+        else if (chunks <= 192) VDB_SCAN(64, 3, 2); else if (chunks <= 256) VDB_SCAN(64, 4, 2); else VDB_SCAN(64, 8, 1);
+#undef VDB_SCAN_Q
 #undef VDB_SCAN
     }
     VDB_HIP(hipGetLastError());

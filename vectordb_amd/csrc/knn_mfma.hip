@@ -22,25 +22,32 @@ constexpr int MT = 32;             // base rows per tile (the M side)
 // lane of the compacting wave.
 template <int KP> struct KnnBuf { static constexpr int CAP = KP == 16 ? 40 : 64, TRIG = CAP - 16; };
 constexpr float INF_F = __builtin_inff();
-constexpr int knn_tile_buffers(int kh) { return kh <= 64 ? 2 : 1; }
 
 // Keeps the KP smallest entries of query `qi`'s candidate buffer, ordered by (ranking key, PointId) — the order of
-// the final result, so rows that tie exactly (repeated vectors) survive by id whatever their slots are.  All lanes of
-// the wave take part; returns the new admission bound: key and id of the KP-th entry once KP are held, else (+inf, 0).
+// the final result, so rows that tie exactly (repeated vectors) survive by id whatever their slots are.  Ids are read
+// only when two entries of the buffer hold the same key.  All lanes of the wave take part; returns the new admission
+// bound: key and row of the KP-th entry once KP are held, else (+inf, NONE32).
 template <int KP, int CAP>
-__device__ __forceinline__ void knn_compact(const GraphView& gv, uint32_t* cnt, uint2* buf, uint32_t qi, float& thr, uint64_t& thr_id) {
+__device__ __forceinline__ void knn_compact(const GraphView& gv, uint32_t* cnt, uint2* buf, uint32_t qi, float& thr, uint32_t& thr_row) {
     const int lane = lane_id();
     const uint32_t n = __builtin_amdgcn_readfirstlane(cnt[qi]);
     uint2 e = make_uint2(0x7f800000u, 0xFFFFFFFFu);
-    uint64_t id = ~0ull;
-    if ((uint32_t)lane < n) { e = buf[qi * CAP + lane]; id = gv.ids[gv.rowmap ? gv.rowmap[e.y] : e.y]; }
+    if ((uint32_t)lane < n) e = buf[qi * CAP + lane];
     const float k = __uint_as_float(e.x);
-    const uint32_t id_lo = (uint32_t)id, id_hi = (uint32_t)(id >> 32);
-    uint32_t rank = 0;
+    uint32_t rank = 0, same = 0;
     for (uint32_t i = 0; i < n; ++i) {
         const float ki = readlane_f(k, (int)i);
-        const uint64_t ii = ((uint64_t)readlane_u(id_hi, (int)i) << 32) | readlane_u(id_lo, (int)i);
-        rank += (ki < k || (ki == k && ii < id)) ? 1u : 0u;
+        rank += ki < k ? 1u : 0u; same += ki == k ? 1u : 0u;
+    }
+    if (__ballot((uint32_t)lane < n && same > 1u)) {           // equal keys: order those by id
+        uint64_t id = ~0ull;
+        if ((uint32_t)lane < n) id = gv.ids[gv.rowmap ? gv.rowmap[e.y] : e.y];
+        const uint32_t id_lo = (uint32_t)id, id_hi = (uint32_t)(id >> 32);
+        for (uint32_t i = 0; i < n; ++i) {
+            const float ki = readlane_f(k, (int)i);
+            const uint64_t ii = ((uint64_t)readlane_u(id_hi, (int)i) << 32) | readlane_u(id_lo, (int)i);
+            rank += (ki == k && ii < id) ? 1u : 0u;
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if ((uint32_t)lane < n && rank < KP) buf[qi * CAP + rank] = e;
@@ -48,11 +55,68 @@ __device__ __forceinline__ void knn_compact(const GraphView& gv, uint32_t* cnt, 
     if (lane == 0) cnt[qi] = kept;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const uint64_t last = __ballot((uint32_t)lane < n && rank == KP - 1);
-    thr = INF_F; thr_id = 0;
+    thr = INF_F; thr_row = NONE32;
     if (last) {
         const int l = __ffsll((unsigned long long)last) - 1;
         thr = readlane_f(k, l);
-        thr_id = ((uint64_t)readlane_u(id_hi, l) << 32) | readlane_u(id_lo, l);
+        thr_row = readlane_u(e.y, l);
+    }
+}
+// Whether row `row`, whose key equals the admission bound, precedes the bound's row by id.
+__device__ __forceinline__ bool knn_tie_admits(const GraphView& gv, uint32_t row, uint32_t thr_row) {
+    if (thr_row == NONE32) return false;
+    return gv.ids[gv.rowmap ? gv.rowmap[row] : row] < gv.ids[gv.rowmap ? gv.rowmap[thr_row] : thr_row];
+}
+
+// Epilogue of one 32-row tile: lane (j, h) holds the ranking keys of query j of its wave against rows
+// row0 + (v / 4) * 8 + h * 4 + v % 4, v = 0..15.  Keys under the query's admission bound go to its candidate buffer.
+// On average about one key of a tile passes somewhere in the wave, so this path runs for most tiles and is kept
+// short: one compare per key, one LDS atomic per lane that has keys to add; keys equal to the bound (repeated
+// vectors) and buffers that fill up before all keys of the tile are in take the branches that are rarely entered.
+template <int KP>
+__device__ __forceinline__ void knn_admit_tile(const GraphView& gv, const float (&key)[16], uint32_t row0, bool qvalid, uint32_t ql,
+                                               uint32_t* cnt, uint2* buf, float& thr, uint32_t& thr_row) {
+    constexpr uint32_t CAP = KnnBuf<KP>::CAP, TRIG = KnnBuf<KP>::TRIG;
+    const int lane = lane_id(), j = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+    uint32_t m = 0, eq = 0;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) { m |= (key[v] < thr ? 1u : 0u) << v; eq |= (key[v] == thr ? 1u : 0u) << v; }
+    if (!qvalid) { m = 0; eq = 0; }
+    if (thr_row == NONE32) eq = 0;                             // no bound yet (+inf): nothing ties with it
+    if (__ballot(eq != 0)) {                                   // a key equal to the bound passes only ahead of the bound's row by id
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+            if (((eq >> v) & 1u) && knn_tie_admits(gv, row0 + (v / 4) * 8 + h * 4 + (v % 4), thr_row)) m |= 1u << v;
+    }
+    while (__ballot(m != 0)) {                                 // one pass, unless a buffer fills before all keys of the tile are in
+        uint32_t held = 0;
+        if (m != 0) {
+            const uint32_t want = (uint32_t)__popc(m);
+            uint32_t pos = atomicAdd(&cnt[ql], want);
+            held = min(pos + want, CAP);
+#pragma unroll
+            for (int v = 0; v < 16; ++v)
+                if (((m >> v) & 1u) && pos < CAP) {
+                    buf[ql * CAP + pos++] = make_uint2(__float_as_uint(key[v]), row0 + (v / 4) * 8 + h * 4 + (v % 4));
+                    m &= ~(1u << v);
+                }
+            if (m != 0) cnt[ql] = CAP;                         // places past the end were counted but not written
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // the later of a query's two lanes saw the earlier one's entries, so the larger `held` is the buffer's fill
+        const uint64_t over = __ballot(held > TRIG);
+        uint32_t need = (uint32_t)over | (uint32_t)(over >> 32);
+        while (need) {
+            const int jj = __ffs(need) - 1; need &= need - 1;
+            float nt; uint32_t ni;
+            knn_compact<KP, (int)CAP>(gv, cnt, buf, wave * 32 + jj, nt, ni);
+            if (j == jj) { thr = nt; thr_row = ni; }
+        }
+        if (m != 0) {                                          // keys still waiting face the renewed bound
+#pragma unroll
+            for (int v = 0; v < 16; ++v)
+                if (((m >> v) & 1u) && !(key[v] < thr || (key[v] == thr && knn_tie_admits(gv, row0 + (v / 4) * 8 + h * 4 + (v % 4), thr_row)))) m &= ~(1u << v);
+        }
     }
 }
 
@@ -85,16 +149,15 @@ __global__ void __launch_bounds__(256) knn_mfma_kernel(GraphView gv, const float
                                                       const float* __restrict__ scale, const float* __restrict__ bias,
                                                       uint32_t* __restrict__ out_slots, uint32_t n_chunks) {
     constexpr int K = 2 * KH, LDA = K + 4;                     // padded tile row: conflict-free 16-byte reads
-    constexpr int KNN_CAP = KnnBuf<KNN_KP>::CAP, KNN_TRIG = KnnBuf<KNN_KP>::TRIG;
+    constexpr int KNN_CAP = KnnBuf<KNN_KP>::CAP;
     constexpr int VPT = K / 32;                                // float4 per thread per tile (256 threads, 32 rows)
-    // Two tile buffers where they fit beside the candidate buffers of two blocks per CU (rows up to 128 floats): the next
-    // tile is written while this one is contracted and one block barrier per tile is enough; one buffer otherwise.
-    constexpr int NBUF = knn_tile_buffers(KH);
+    // One tile buffer and two block barriers per tile: a second buffer with one barrier per tile measured 5 % slower
+    // (28.7 against 27.4 ms per 10k x 1M x 128 batch) and its LDS would leave room for one block per CU only.
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* At = reinterpret_cast<float*>(smem);                                  // NBUF x MT x LDA
-    float* sc_t = At + NBUF * MT * LDA;                                          // NBUF x MT
-    float* bi_t = sc_t + NBUF * MT;                                              // NBUF x MT
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(bi_t + NBUF * MT);               // MQ
+    float* At = reinterpret_cast<float*>(smem);                                  // MT x LDA
+    float* sc_t = At + MT * LDA;                                                 // MT
+    float* bi_t = sc_t + MT;                                                     // MT
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(bi_t + MT);                      // MQ
     uint2* buf = reinterpret_cast<uint2*>(cnt + MQ);                             // MQ x KNN_CAP {key bits, row}
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -111,7 +174,7 @@ __global__ void __launch_bounds__(256) knn_mfma_kernel(GraphView gv, const float
         b[s] = (q < nq && d < dim) ? queries[(size_t)q * dim + d] : 0.f;
     }
     if (tid < MQ) cnt[tid] = 0;
-    float thr = INF_F; uint64_t thr_id = 0;      // admission bound of this lane's query: (key, id) of its KP-th candidate
+    float thr = INF_F; uint32_t thr_row = NONE32;  // admission bound of this lane's query: key and row of its KP-th candidate
 
     const uint32_t per = (((gv.n + n_chunks - 1) / n_chunks) + MT - 1) / MT * MT;
     const uint32_t r_begin = blockIdx.x * per, r_end = min(gv.n, r_begin + per);
@@ -131,35 +194,23 @@ __global__ void __launch_bounds__(256) knn_mfma_kernel(GraphView gv, const float
         }
         if (tid < MT) { const uint32_t rr = tile_base + tid; st_sc = rr < r_end ? scale[rr] : 0.f; st_bi = rr < r_end ? bias[rr] : INF_F; }
     };
-    auto stash = [&](uint32_t ib) {
+    auto stash = [&]() {
 #pragma unroll
-        for (int v = 0; v < VPT; ++v) *reinterpret_cast<float4*>(At + ib * (MT * LDA) + lrow * LDA + lpart * (K / 8) + v * 4) = stage[v];
-        if (tid < MT) { sc_t[ib * MT + tid] = st_sc; bi_t[ib * MT + tid] = st_bi; }
+        for (int v = 0; v < VPT; ++v) *reinterpret_cast<float4*>(At + lrow * LDA + lpart * (K / 8) + v * 4) = stage[v];
+        if (tid < MT) { sc_t[tid] = st_sc; bi_t[tid] = st_bi; }
     };
 
 
     if (r_begin < r_end) fetch(r_begin);
-    if (NBUF == 2) {
-        if (r_begin < r_end) stash(0);
-        __syncthreads();
-        if (r_begin + MT < r_end) fetch(r_begin + MT);
-    }
-    uint32_t ib = 0;
     for (uint32_t tb = r_begin; tb < r_end; tb += MT) {
-        if (NBUF == 1) {
-            __syncthreads();                           // the previous tile has been consumed
-            stash(0);
-            __syncthreads();
-            if (tb + MT < r_end) fetch(tb + MT);       // in flight during the contraction
-        } else {
-            // the other buffer was last read during the previous tile, which every wave left through the barrier below
-            if (tb + MT < r_end) stash(ib ^ 1u);
-            if (tb + 2 * MT < r_end) fetch(tb + 2 * MT);
-        }
+        __syncthreads();                               // the previous tile has been consumed
+        stash();
+        __syncthreads();
+        if (tb + MT < r_end) fetch(tb + MT);           // in flight during the contraction
         floatx16 acc;
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[v] = 0.f;
-        const float* arow = At + ib * (MT * LDA) + j * LDA + h * KH;
+        const float* arow = At + j * LDA + h * KH;
         float4 afrag[KH / 4];                     // the lane's whole slice of the tile: reads run ahead of the MFMAs
 #pragma unroll
         for (int c = 0; c < KH / 4; ++c) afrag[c] = *reinterpret_cast<const float4*>(arow + 4 * c);
@@ -175,49 +226,21 @@ __global__ void __launch_bounds__(256) knn_mfma_kernel(GraphView gv, const float
         float key[16];
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            const float4 s4 = *reinterpret_cast<const float4*>(sc_t + ib * MT + g4 * 8 + h * 4);
-            const float4 b4 = *reinterpret_cast<const float4*>(bi_t + ib * MT + g4 * 8 + h * 4);
+            const float4 s4 = *reinterpret_cast<const float4*>(sc_t + g4 * 8 + h * 4);
+            const float4 b4 = *reinterpret_cast<const float4*>(bi_t + g4 * 8 + h * 4);
             key[g4 * 4 + 0] = __builtin_fmaf(acc[g4 * 4 + 0], s4.x, b4.x);
             key[g4 * 4 + 1] = __builtin_fmaf(acc[g4 * 4 + 1], s4.y, b4.y);
             key[g4 * 4 + 2] = __builtin_fmaf(acc[g4 * 4 + 2], s4.z, b4.z);
             key[g4 * 4 + 3] = __builtin_fmaf(acc[g4 * 4 + 3], s4.w, b4.w);
         }
-#pragma unroll
-        for (int hv = 0; hv < 2; ++hv) {           // rows in two halves: at most 16 pushes per query between compactions
-            bool any2 = false;
-#pragma unroll
-            for (int v = hv * 8; v < hv * 8 + 8; ++v) any2 = any2 || key[v] <= thr;
-            if (q >= nq) any2 = false;
-            if (__ballot(any2)) {
-                if (any2) {
-#pragma unroll
-                    for (int v = hv * 8; v < hv * 8 + 8; ++v) {
-                        const uint32_t row = tb + (v / 4) * 8 + h * 4 + (v % 4);
-                        if (key[v] < thr || (key[v] == thr && thr_id != 0 && gv.ids[gv.rowmap ? gv.rowmap[row] : row] < thr_id)) {
-                            const uint32_t pos = atomicAdd(&cnt[ql], 1u);
-                            buf[ql * KNN_CAP + pos] = make_uint2(__float_as_uint(key[v]), row);
-                        }
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                // queries of this wave whose buffer could not take another half tile
-                uint64_t need = __ballot(lane < 32 && cnt[wave * 32 + (lane & 31)] > KNN_TRIG);
-                while (need) {
-                    const int jj = __ffsll((unsigned long long)need) - 1; need &= need - 1;
-                    float nt; uint64_t ni;
-                    knn_compact<KNN_KP, KNN_CAP>(gv, cnt, buf, wave * 32 + jj, nt, ni);
-                    if (j == jj) { thr = nt; thr_id = ni; }
-                }
-            }
-        }
-        if (NBUF == 2) { __syncthreads(); ib ^= 1u; }  // this tile is consumed, the next one is complete
+        knn_admit_tile<KNN_KP>(gv, key, tb, q < nq, ql, cnt, buf, thr, thr_row);
     }
     // hand over: KNN_KP slots per (query, chunk), NONE32 marks unused entries
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     for (int jj = 0; jj < 32; ++jj) {
         const uint32_t qi = wave * 32 + jj, qg = blockIdx.y * MQ + qi;
         if (qg >= nq) break;
-        if (cnt[qi] > KNN_KP) { float nt; uint64_t ni; knn_compact<KNN_KP, KNN_CAP>(gv, cnt, buf, qi, nt, ni); }
+        if (cnt[qi] > KNN_KP) { float nt; uint32_t ni; knn_compact<KNN_KP, KNN_CAP>(gv, cnt, buf, qi, nt, ni); }
         const uint32_t n = cnt[qi];
         if (lane < KNN_KP) out_slots[((size_t)qg * n_chunks + blockIdx.x) * KNN_KP + lane] = (uint32_t)lane < n ? buf[qi * KNN_CAP + lane].y : NONE32;
     }
@@ -234,7 +257,7 @@ template <int KNN_KP>
 __global__ void __launch_bounds__(256) knn_mfma_long_kernel(GraphView gv, const float* __restrict__ queries, uint32_t nq,
                                                            const float* __restrict__ scale, const float* __restrict__ bias,
                                                            uint32_t* __restrict__ out_slots, uint32_t n_chunks) {
-    constexpr int KNN_CAP = KnnBuf<KNN_KP>::CAP, KNN_TRIG = KnnBuf<KNN_KP>::TRIG;
+    constexpr int KNN_CAP = KnnBuf<KNN_KP>::CAP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* At = reinterpret_cast<float*>(smem);                                  // 2 x LT x LDK
     float* sc_t = At + 2 * LT * LDK;                                             // LT
@@ -253,7 +276,7 @@ __global__ void __launch_bounds__(256) knn_mfma_long_kernel(GraphView gv, const 
     const uint32_t nkc = (stride + KC - 1) / KC;
 
     if (tid < MQ) cnt[tid] = 0;
-    float thr = INF_F; uint64_t thr_id = 0;      // admission bound of this lane's query: (key, id) of its KP-th candidate
+    float thr = INF_F; uint32_t thr_row = NONE32;  // admission bound of this lane's query: key and row of its KP-th candidate
     const uint32_t per = (((gv.n + n_chunks - 1) / n_chunks) + LT - 1) / LT * LT;
     const uint32_t r_begin = blockIdx.x * per, r_end = min(gv.n, r_begin + per);
     const int lrow = tid >> 1, lhalf = tid & 1;          // loader: thread t brings 16 floats of tile row t / 2
@@ -330,40 +353,14 @@ __global__ void __launch_bounds__(256) knn_mfma_long_kernel(GraphView gv, const 
                 key[g4 * 4 + 2] = __builtin_fmaf(acc[t][g4 * 4 + 2], s4.z, b4.z);
                 key[g4 * 4 + 3] = __builtin_fmaf(acc[t][g4 * 4 + 3], s4.w, b4.w);
             }
-#pragma unroll
-            for (int hv = 0; hv < 2; ++hv) {
-                bool any2 = false;
-#pragma unroll
-                for (int v = hv * 8; v < hv * 8 + 8; ++v) any2 = any2 || key[v] <= thr;
-                if (!qin) any2 = false;
-                if (__ballot(any2)) {
-                    if (any2) {
-#pragma unroll
-                        for (int v = hv * 8; v < hv * 8 + 8; ++v) {
-                            const uint32_t row = tb + t * 32 + (v / 4) * 8 + h * 4 + (v % 4);
-                            if (key[v] < thr || (key[v] == thr && thr_id != 0 && gv.ids[gv.rowmap ? gv.rowmap[row] : row] < thr_id)) {
-                                const uint32_t pos = atomicAdd(&cnt[ql], 1u);
-                                buf[ql * KNN_CAP + pos] = make_uint2(__float_as_uint(key[v]), row);
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    uint64_t need = __ballot(lane < 32 && cnt[wave * 32 + (lane & 31)] > KNN_TRIG);
-                    while (need) {
-                        const int jj = __ffsll((unsigned long long)need) - 1; need &= need - 1;
-                        float nt; uint64_t ni;
-                        knn_compact<KNN_KP, KNN_CAP>(gv, cnt, buf, wave * 32 + jj, nt, ni);
-                        if (j == jj) { thr = nt; thr_id = ni; }
-                    }
-                }
-            }
+            knn_admit_tile<KNN_KP>(gv, key, tb + t * 32, qin, ql, cnt, buf, thr, thr_row);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     for (int jj = 0; jj < 32; ++jj) {
         const uint32_t qi = wave * 32 + jj, qg = blockIdx.y * MQ + qi;
         if (qg >= nq) break;
-        if (cnt[qi] > KNN_KP) { float nt; uint64_t ni; knn_compact<KNN_KP, KNN_CAP>(gv, cnt, buf, qi, nt, ni); }
+        if (cnt[qi] > KNN_KP) { float nt; uint32_t ni; knn_compact<KNN_KP, KNN_CAP>(gv, cnt, buf, qi, nt, ni); }
         const uint32_t n = cnt[qi];
         if (lane < KNN_KP) out_slots[((size_t)qg * n_chunks + blockIdx.x) * KNN_KP + lane] = (uint32_t)lane < n ? buf[qi * KNN_CAP + lane].y : NONE32;
     }
@@ -466,7 +463,7 @@ uint32_t resident_blocks(Kernel kernel, size_t lds) {
 template <int KH, int KP>
 uint32_t launch_mfma(const GraphView& g, const float* queries, uint32_t nq, const float* scale, const float* bias, uint32_t* slots, uint32_t max_chunks, hipStream_t st) {
     constexpr int K = 2 * KH;
-    const size_t lds = (size_t)knn_tile_buffers(KH) * ((size_t)MT * (K + 4) * 4 + 2 * MT * 4) + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8;
+    const size_t lds = ((size_t)MT * (K + 4) * 4 + 2 * MT * 4) + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8;
     const uint32_t n_chunks = pick_chunks(g.n, nq, resident_blocks(knn_mfma_kernel<KH, KP>, lds), max_chunks);
     hipLaunchKernelGGL((knn_mfma_kernel<KH, KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, queries, nq, scale, bias, slots, n_chunks);
     return n_chunks;
