@@ -133,7 +133,7 @@ def test_wide_steps_keep_recall_and_distances(ora, vdb, metric, width):
     exact, exact_n = h.exact_knn_batch(q, k)
     p = vdb.HNSWIndex(metric, 16, 64, 16, d, seed=1, arith=vdb.Arith.Fast, beam_width=width)
     p.import_graph(h.export_graph())
-    for ef in (32, 64, 200):
+    for ef in (32, 64, 200, 320, 512):                            # 320 and 512: register lists of six and eight chunks
         ref, refn = h.search_batch(q, k, ef_search=ef)
         got, gotn, st = p.search_batch(q, k, ef_search=ef, with_stats=True)
         assert np.array_equal(refn, gotn) and not (st["flags"] & 1).any()

@@ -76,13 +76,16 @@ struct SearchArgs {
 // flags reported per query in vdb_query_stats.flags
 enum : uint32_t { QF_HASH_OVERFLOW = 1u, QF_FILTER_ERROR = 2u, QF_CAND_OVERFLOW = 4u };
 
-// 64-entry chunks of the register-resident layer-0 result list (FAST arithmetic; unfiltered search,
-// graph construction and the masked filtered walk; ef up to 256); 0 = the list lives in LDS.
+// 64-entry chunks of the register-resident layer-0 result list (FAST arithmetic; unfiltered search up to ef 512 in
+// lists of 1, 2, 3, 4, 6 or 8 chunks; graph construction and the masked filtered walk up to ef 256); 0 = the list
+// lives in LDS.
 inline uint32_t reg_list_chunks(const SearchArgs& a) {
     // (the masked walk keeps its passing list in one 64-entry register chunk: top_k up to 64)
     const bool mode_ok = a.mode == MODE_SEARCH || a.mode == MODE_BUILD || (a.mode == MODE_MASKED && a.top_k <= 64);
-    if (a.force_generic || ((uint64_t)a.g.n >> (a.tag_log2 + 13)) != 0 || a.arith != VDB_ARITH_FAST || !mode_ok || a.ef == 0 || a.ef > 256) return 0;
-    return (a.ef + 63u) / 64u;
+    const uint32_t ef_max = a.mode == MODE_SEARCH ? 512u : 256u;
+    if (a.force_generic || ((uint64_t)a.g.n >> (a.tag_log2 + 13)) != 0 || a.arith != VDB_ARITH_FAST || !mode_ok || a.ef == 0 || a.ef > ef_max) return 0;
+    const uint32_t c = (a.ef + 63u) / 64u;
+    return c <= 4 ? c : (c <= 6 ? 6u : 8u);
 }
 
 void launch_search(const SearchArgs& a, hipStream_t s);

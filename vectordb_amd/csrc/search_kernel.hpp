@@ -966,6 +966,8 @@ void launch_search_fast(const SearchArgs& a, size_t lds, hipStream_t st) {
             case 2: launch_search_shape<MODE, METRIC, 2>(a, lds, st); return;
             case 3: launch_search_shape<MODE, METRIC, 3>(a, lds, st); return;
             case 4: launch_search_shape<MODE, METRIC, 4>(a, lds, st); return;
+            case 6: if constexpr (MODE == MODE_SEARCH) { launch_search_shape<MODE, METRIC, 6>(a, lds, st); return; } break;
+            case 8: if constexpr (MODE == MODE_SEARCH) { launch_search_shape<MODE, METRIC, 8>(a, lds, st); return; } break;
             default: break;
         }
     }
