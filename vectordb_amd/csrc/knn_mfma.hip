@@ -79,6 +79,13 @@ __device__ __forceinline__ void knn_admit_tile(const GraphView& gv, const float 
     constexpr uint32_t CAP = KnnBuf<KP>::CAP, TRIG = KnnBuf<KP>::TRIG;
     const int lane = lane_id(), j = lane & 31, h = lane >> 5;
     const uint32_t ql = qbase + j;                             // this lane's query within the block; qbase: the wave's first
+    // fp32 MFMAs and vector instructions share a SIMD's issue slot (tools/mfma_interleave.hip), so every instruction
+    // here is paid in full: the common case — nothing of the tile passes anywhere in the wave — costs the minimum of
+    // the 16 keys and one compare
+    float mn = key[0];
+#pragma unroll
+    for (int v = 1; v < 16; ++v) mn = __builtin_fminf(mn, key[v]);
+    if (!__ballot(qvalid && mn <= thr)) return;
     uint32_t m = 0, eq = 0;
 #pragma unroll
     for (int v = 0; v < 16; ++v) { m |= (key[v] < thr ? 1u : 0u) << v; eq |= (key[v] == thr ? 1u : 0u) << v; }
