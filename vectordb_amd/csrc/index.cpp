@@ -715,7 +715,7 @@ void vdb_index::exact_knn(const float* q, size_t nq, size_t top_k, bool dev, vdb
     const bool mfma = opts.arith == VDB_ARITH_FAST && knn_mfma_supported(g, (uint32_t)top_k) && !std::getenv("VDB_KNN_STRICT");
     const uint32_t chunks = exact_knn_chunks(g.n);
     DevBuf<uint32_t>& words = s_knn_words_by_stream[s]; DevBuf<vdb_scored_point>& lists = s_knn_by_stream[s];
-    if (mfma) words.reserve(knn_mfma_scratch_words(g.n, (uint32_t)nq), s, false);
+    if (mfma) words.reserve(knn_mfma_scratch_words(g.n, (uint32_t)nq, g.stride), s, false);
     else lists.reserve(nq * chunks * top_k, s, false);
     auto run = [&](const float* dq, vdb_scored_point* dout, uint32_t* dn) {
         if (mfma) launch_exact_knn_mfma(g, dq, (uint32_t)nq, (uint32_t)top_k, dout, dn, words.p, s);

@@ -112,7 +112,7 @@ void launch_patch_entries(uint32_t* adj0, const uint32_t* slot, const uint32_t* 
 uint32_t exact_knn_chunks(uint32_t n);
 // FAST exact k-NN: fp32 MFMA candidate pass + strict re-rank (knn_mfma.hip).  scratch holds knn_mfma_scratch_words() dwords.
 bool knn_mfma_supported(const GraphView& g, uint32_t top_k);
-size_t knn_mfma_scratch_words(uint32_t n, uint32_t nq);
+size_t knn_mfma_scratch_words(uint32_t n, uint32_t nq, uint32_t stride);
 void launch_exact_knn_mfma(const GraphView& g, const float* queries, uint32_t nq, uint32_t top_k, vdb_scored_point* out, uint32_t* out_n,
                            uint32_t* scratch, hipStream_t s);
 // The same pass on a static scratch area inside the library's code object (no allocation; 16 MiB per GPU, shared by every

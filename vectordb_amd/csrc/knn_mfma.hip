@@ -7,6 +7,7 @@
 // one chunk fall within the fp32 rounding error of the contraction (~1e-6 relative) of it.
 #include "device_common.hpp"
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 
 namespace vdb {
@@ -260,6 +261,140 @@ __global__ void __launch_bounds__(256) knn_mfma_kernel(GraphView gv, const float
     }
 }
 
+// ---- candidate pass on the bf16 matrix pipe -------------------------------------------------------------------
+// Every fp32 value is split into a bf16 high part and a bf16 remainder, x = xh + xl + O(2^-17 |x|), and a product
+// q.x is taken as qh.xh + qh.xl + ql.xh (v_mfma_f32_32x32x16_bf16, fp32 accumulation): the dropped ql.xl and the
+// split residuals leave an error below 2^-14 of sum |q_i x_i| in the worst case, about 2^-17 typically, where three
+// bf16 MFMAs take 98 clocks per 16 dimensions against 512 for the eight fp32 MFMAs they replace.  The keys only
+// select candidates: the strict re-rank scores whatever is kept, so an error moves the boundary of a chunk's KP
+// candidates, not a result — a true neighbour is lost only if more than KP - top_k rows of one chunk lie within that
+// error of it.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void bf16_split(float x, __bf16& h, __bf16& l) { h = (__bf16)x; l = (__bf16)(x - (float)h); }
+
+// queries -> two planes (high parts, remainders) of nq x kq bf16, zero beyond dim
+__global__ void __launch_bounds__(256) knn_split_queries_kernel(const float* __restrict__ queries, uint32_t nq, uint32_t dim, uint32_t kq,
+                                                               __bf16* __restrict__ qh, __bf16* __restrict__ ql) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)nq * kq) return;
+    const uint32_t q = (uint32_t)(i / kq), d = (uint32_t)(i % kq);
+    const float x = d < dim ? queries[(size_t)q * dim + d] : 0.f;
+    __bf16 h, l; bf16_split(x, h, l);
+    qh[i] = h; ql[i] = l;
+}
+
+// grid (n_chunks, ceil(nq / MQ)), 256 threads.  KS = 16-dimension steps of the row (padded row = 16 KS floats).  Lane
+// (j, h) of a wave holds, per step, dimensions 16 s + 8 h .. + 8 of query j (B operand, registers) and of tile row j
+// (A operand, read from the tile's two bf16 planes in LDS); the accumulator layout is that of the fp32 32x32 MFMA.
+template <int KS, int KNN_KP>
+__global__ void __launch_bounds__(256) knn_bf16_kernel(GraphView gv, const __bf16* __restrict__ qh, const __bf16* __restrict__ ql, uint32_t nq,
+                                                      const float* __restrict__ scale, const float* __restrict__ bias,
+                                                      uint32_t* __restrict__ out_slots, uint32_t n_chunks) {
+    constexpr int K = 16 * KS, LDB = K + 8;                    // bf16 per tile row, padded by 16 bytes: conflict-free 16-byte reads
+    constexpr int KNN_CAP = KnnBuf<KNN_KP>::CAP;
+    constexpr int CPT = K / 8;                                 // floats per loading thread: eight threads per tile row
+    constexpr int VPT = CPT / 4;                               // float4 per thread per tile
+    static_assert(VPT >= 2 && VPT % 2 == 0, "a loading thread writes 16 bytes per plane at a time");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __bf16* Ah = reinterpret_cast<__bf16*>(smem);                                // MT x LDB high parts
+    __bf16* Al = Ah + MT * LDB;                                                  // MT x LDB remainders
+    float* sc_t = reinterpret_cast<float*>(Al + MT * LDB);                       // MT
+    float* bi_t = sc_t + MT;                                                     // MT
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(bi_t + MT);                      // MQ
+    uint2* buf = reinterpret_cast<uint2*>(cnt + MQ);                             // MQ x KNN_CAP {key bits, row}
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const uint32_t stride = gv.stride;
+    const uint32_t q = blockIdx.y * MQ + wave * 32 + j;        // this lane's query (two lanes per query)
+
+    bf16x8 bh[KS], bl[KS];                                     // B operand: the whole query stays in registers
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const size_t off = (size_t)(q < nq ? q : 0) * K + 16 * s + 8 * h;
+        bh[s] = *reinterpret_cast<const bf16x8*>(qh + off);
+        bl[s] = *reinterpret_cast<const bf16x8*>(ql + off);
+    }
+    if (tid < MQ) cnt[tid] = 0;
+    float thr = INF_F; uint32_t thr_row = NONE32;  // admission bound of this lane's query: key and row of its KP-th candidate
+
+    const uint32_t per = (((gv.n + n_chunks - 1) / n_chunks) + MT - 1) / MT * MT;
+    const uint32_t r_begin = blockIdx.x * per, r_end = min(gv.n, r_begin + per);
+    // loader: thread t brings columns [part * CPT, + CPT) of tile row t / 8
+    const int lrow = tid >> 3, lpart = tid & 7;
+    float4 stage[VPT];
+    float st_sc = 0.f, st_bi = INF_F;
+    auto fetch = [&](uint32_t tile_base) {
+        const uint32_t r = tile_base + lrow;
+        const bool in = r < r_end;
+        const uint32_t rp = in ? r : r_begin;
+        const float* row = gv.vecs + (size_t)(gv.rowmap ? gv.rowmap[rp] : rp) * stride;
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            const uint32_t c = lpart * CPT + v * 4;
+            stage[v] = (in && c < stride) ? *reinterpret_cast<const float4*>(row + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (tid < MT) { const uint32_t rr = tile_base + tid; st_sc = rr < r_end ? scale[rr] : 0.f; st_bi = rr < r_end ? bias[rr] : INF_F; }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int v = 0; v < VPT; v += 2) {
+            const float x[8] = {stage[v].x, stage[v].y, stage[v].z, stage[v].w, stage[v + 1].x, stage[v + 1].y, stage[v + 1].z, stage[v + 1].w};
+            bf16x8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { __bf16 a, b; bf16_split(x[e], a, b); hi[e] = a; lo[e] = b; }
+            const int at = lrow * LDB + lpart * CPT + v * 4;
+            *reinterpret_cast<bf16x8*>(Ah + at) = hi;
+            *reinterpret_cast<bf16x8*>(Al + at) = lo;
+        }
+        if (tid < MT) { sc_t[tid] = st_sc; bi_t[tid] = st_bi; }
+    };
+
+    if (r_begin < r_end) fetch(r_begin);
+    for (uint32_t tb = r_begin; tb < r_end; tb += MT) {
+        __syncthreads();                               // the previous tile has been consumed
+        stash();
+        __syncthreads();
+        if (tb + MT < r_end) fetch(tb + MT);           // in flight during the contraction
+        floatx16 acc;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+        const __bf16* arh = Ah + j * LDB + 8 * h;
+        const __bf16* arl = Al + j * LDB + 8 * h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(arh + 16 * s);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(arl + 16 * s);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[s], acc, 0, 0, 0);
+        }
+        // epilogue: acc[v] = q_j . x_i with i = (v/4)*8 + h*4 + v%4
+        float key[16];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 s4 = *reinterpret_cast<const float4*>(sc_t + g4 * 8 + h * 4);
+            const float4 b4 = *reinterpret_cast<const float4*>(bi_t + g4 * 8 + h * 4);
+            key[g4 * 4 + 0] = __builtin_fmaf(acc[g4 * 4 + 0], s4.x, b4.x);
+            key[g4 * 4 + 1] = __builtin_fmaf(acc[g4 * 4 + 1], s4.y, b4.y);
+            key[g4 * 4 + 2] = __builtin_fmaf(acc[g4 * 4 + 2], s4.z, b4.z);
+            key[g4 * 4 + 3] = __builtin_fmaf(acc[g4 * 4 + 3], s4.w, b4.w);
+        }
+        knn_admit_tile<KNN_KP>(gv, key, tb, q < nq, (uint32_t)wave * 32, cnt, buf, thr, thr_row);
+    }
+    // hand over: KNN_KP slots per (query, chunk), NONE32 marks unused entries
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int jj = 0; jj < 32; ++jj) {
+        const uint32_t qi = wave * 32 + jj, qg = blockIdx.y * MQ + qi;
+        if (qg >= nq) break;
+        if (cnt[qi] > KNN_KP) { float nt; uint32_t ni; knn_compact<KNN_KP, KNN_CAP>(gv, cnt, buf, qi, nt, ni); }
+        const uint32_t n = cnt[qi];
+        if (lane < KNN_KP) out_slots[((size_t)qg * n_chunks + blockIdx.x) * KNN_KP + lane] = (uint32_t)lane < n ? buf[qi * KNN_CAP + lane].y : NONE32;
+    }
+}
+
 // Rows longer than 256 floats: the contraction runs over the row in chunks of KC floats with the
 // accumulators kept in registers.  A block handles LT = 128 base rows (four 32x32 tiles per wave,
 // i.e. four independent MFMA chains) against MQ = 128 queries; per chunk the A slice (LT x KC) goes
@@ -482,6 +617,22 @@ uint32_t launch_mfma(const GraphView& g, const float* queries, uint32_t nq, cons
     hipLaunchKernelGGL((knn_mfma_kernel<KH, KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, queries, nq, scale, bias, slots, n_chunks);
     return n_chunks;
 }
+// padded row length of the bf16 planes of the queries (0: the shape runs on the fp32 kernels)
+inline uint32_t knn_bf16_k(uint32_t stride) { return stride <= 64 ? 64u : stride <= 128 ? 128u : stride <= 256 ? 256u : 0u; }
+template <int KS, int KP>
+uint32_t launch_bf16(const GraphView& g, const __bf16* qh, const __bf16* ql, uint32_t nq, const float* scale, const float* bias, uint32_t* slots, uint32_t max_chunks, hipStream_t st) {
+    constexpr int K = 16 * KS;
+    const size_t lds = (size_t)2 * MT * (K + 8) * 2 + 2 * MT * 4 + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8;
+    const uint32_t n_chunks = pick_chunks(g.n, nq, resident_blocks(knn_bf16_kernel<KS, KP>, lds), max_chunks);
+    hipLaunchKernelGGL((knn_bf16_kernel<KS, KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, qh, ql, nq, scale, bias, slots, n_chunks);
+    return n_chunks;
+}
+template <int KP>
+uint32_t launch_bf16_any(const GraphView& g, const __bf16* qh, const __bf16* ql, uint32_t nq, const float* scale, const float* bias, uint32_t* slots, uint32_t max_chunks, hipStream_t st) {
+    if (g.stride <= 64) return launch_bf16<4, KP>(g, qh, ql, nq, scale, bias, slots, max_chunks, st);
+    if (g.stride <= 128) return launch_bf16<8, KP>(g, qh, ql, nq, scale, bias, slots, max_chunks, st);
+    return launch_bf16<16, KP>(g, qh, ql, nq, scale, bias, slots, max_chunks, st);
+}
 template <int KP>
 uint32_t launch_mfma_any(const GraphView& g, const float* queries, uint32_t nq, const float* scale, const float* bias, uint32_t* slots, uint32_t max_chunks, hipStream_t st) {
     if (g.stride <= 64) return launch_mfma<32, KP>(g, queries, nq, scale, bias, slots, max_chunks, st);
@@ -498,18 +649,33 @@ inline uint32_t knn_kp(uint32_t top_k) { return top_k + 4 <= 16 ? 16u : 32u; }
 
 bool knn_mfma_supported(const GraphView& g, uint32_t top_k) { return top_k >= 1 && top_k + 4 <= 32 && g.stride <= MAX_DIM && g.n > 0; }
 // room for the largest chunk count and candidate width the launch may pick
-size_t knn_mfma_scratch_words(uint32_t n, uint32_t nq) { return 2 * (size_t)n + (size_t)nq * std::max<uint32_t>(1, std::min<uint32_t>(64, n / 4096)) * 32; }
+// words of the fixed part of the scratch: row scale and bias (rounded up to 16 bytes) and the two bf16 planes of the queries
+static size_t knn_fixed_words(uint32_t n, uint32_t nq, uint32_t stride) { return ((2 * (size_t)n + 3) & ~size_t(3)) + (size_t)nq * knn_bf16_k(stride); }
+size_t knn_mfma_scratch_words(uint32_t n, uint32_t nq, uint32_t stride) {
+    return knn_fixed_words(n, nq, stride) + (size_t)nq * std::max<uint32_t>(1, std::min<uint32_t>(64, n / 4096)) * 32;
+}
 
-// scratch: [scale n][bias n][candidate slots: nq x chunks x KP], chunks <= max_chunks
+// scratch: [scale n][bias n][query planes: 2 x nq x K bf16][candidate slots: nq x chunks x KP], chunks <= max_chunks
 static void run_exact_knn_mfma(const GraphView& g, const float* queries, uint32_t nq, uint32_t top_k, vdb_scored_point* out, uint32_t* out_n,
                                uint32_t* scratch, uint32_t max_chunks, hipStream_t st) {
     float* scale = reinterpret_cast<float*>(scratch); float* bias = scale + g.n;
-    uint32_t* slots = scratch + 2 * (size_t)g.n;
+    const uint32_t kq = std::getenv("VDB_KNN_FP32") ? 0u : knn_bf16_k(g.stride);
+    __bf16* qh = reinterpret_cast<__bf16*>(scratch + ((2 * (size_t)g.n + 3) & ~size_t(3))); __bf16* ql = qh + (size_t)nq * knn_bf16_k(g.stride);
+    uint32_t* slots = scratch + knn_fixed_words(g.n, nq, g.stride);
     hipLaunchKernelGGL(knn_prepare_kernel, dim3((g.n + 31) / 32), dim3(256), 0, st, g, scale, bias);
     VDB_HIP(hipGetLastError());
     const uint32_t kp = knn_kp(top_k);
-    const uint32_t n_chunks = kp == 16 ? launch_mfma_any<16>(g, queries, nq, scale, bias, slots, max_chunks, st)
-                                       : launch_mfma_any<32>(g, queries, nq, scale, bias, slots, max_chunks, st);
+    uint32_t n_chunks;
+    if (kq) {
+        const size_t cells = (size_t)nq * kq;
+        hipLaunchKernelGGL(knn_split_queries_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, queries, nq, g.dim, kq, qh, ql);
+        VDB_HIP(hipGetLastError());
+        n_chunks = kp == 16 ? launch_bf16_any<16>(g, qh, ql, nq, scale, bias, slots, max_chunks, st)
+                            : launch_bf16_any<32>(g, qh, ql, nq, scale, bias, slots, max_chunks, st);
+    } else {
+        n_chunks = kp == 16 ? launch_mfma_any<16>(g, queries, nq, scale, bias, slots, max_chunks, st)
+                            : launch_mfma_any<32>(g, queries, nq, scale, bias, slots, max_chunks, st);
+    }
     VDB_HIP(hipGetLastError());
     const size_t lds = (size_t)g.stride * 4 + (size_t)top_k * 16;
     hipLaunchKernelGGL(knn_rerank_kernel, dim3(nq), dim3(64), lds, st, g, queries, top_k, slots, n_chunks * kp, out, out_n);
@@ -556,9 +722,9 @@ void launch_exact_knn_mfma_static(const GraphView& g, const float* queries, uint
                                   hipStream_t st) {
     if (nq == 0) return;
     const uint32_t kp = knn_kp(top_k);
-    const size_t fixed = 2 * (size_t)g.n, per_chunk = (size_t)nq * kp;
+    const size_t fixed = knn_fixed_words(g.n, nq, g.stride), per_chunk = (size_t)nq * kp;
     if (fixed + per_chunk > KNN_STATIC_WORDS)
-        throw Failure(err_arg("exact k-NN without allocation: 2 * rows + queries * " + std::to_string(kp) + " = " + std::to_string(fixed + per_chunk) +
+        throw Failure(err_arg("exact k-NN without allocation: 2 * rows + queries * (" + std::to_string(kp) + " + padded row length up to 256) = " + std::to_string(fixed + per_chunk) +
                               " words exceed the static scratch of " + std::to_string(KNN_STATIC_WORDS) + " words (16 MiB); use vdb_index_exact_knn_batch_dev"));
     const uint32_t max_chunks = (uint32_t)std::min<size_t>(64, (KNN_STATIC_WORDS - fixed) / per_chunk);
     run_exact_knn_mfma(g, queries, nq, top_k, out, out_n, knn_static_scratch_ptr(), max_chunks, st);
