@@ -28,14 +28,15 @@ def kernel_us(df, part):
 ks = stats("knn_trace", f"profiles/{tag}_exact_knn_128_kernel_stats.csv")
 ks7 = stats("knn768_trace", f"profiles/{tag}_exact_knn_768_kernel_stats.csv")
 b = last_json(f"{src}/knn_trace.json"); b7 = last_json(f"{src}/knn768_trace.json")
-sq = counters("knn_sq", "knn_mfma_kernel"); gr = counters("knn_grbm", "knn_mfma_kernel")
-mf = ks[ks.Name.str.contains("knn_mfma_kernel", regex=False)].iloc[0]
+cand = [n for n in ks.Name if "knn_bf16_kernel" in n or "knn_mfma_kernel" in n][0].split("(")[0].split("::")[-1].split("<")[0]   # the candidate-pass kernel of this build
+sq = counters("knn_sq", cand); gr = counters("knn_grbm", cand)
+mf = ks[ks.Name.str.contains(cand, regex=False)].iloc[0]
 mfma_us = mf.AverageNs / 1e3
 flop = 2.0 * 10000 * 1_000_000 * 128
 clock = gr["GRBM_GUI_ACTIVE"] / 8 / mfma_us / 1e3
 knn = {"command": f"tools/collect_aux_profiles.sh {tag}", "workload_128": b, "workload_768": b7,
        "kernels_128_us": kernel_us(ks, "knn_"), "kernels_768_us": kernel_us(ks7, "knn_"),
-       "candidate_pass_128": {"avg_us": mfma_us, "tflops": flop / mfma_us / 1e6, "frac_of_157.3": flop / mfma_us / 1e6 / 157.3,
+       "candidate_pass_128": {"kernel": mf.Name.split("(")[0], "avg_us": mfma_us, "tflops": flop / mfma_us / 1e6, "frac_of_157.3": flop / mfma_us / 1e6 / 157.3,
                               "counters_per_launch": sq, "clock_GHz": clock,
                               "mfma_busy_share (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles))": sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * mfma_us * 1e3 * clock),
                               "non_mfma_valu_per_mfma": (sq["SQ_INSTS_VALU"] - sq["SQ_INSTS_MFMA"]) / sq["SQ_INSTS_MFMA"]}}

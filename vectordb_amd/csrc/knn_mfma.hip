@@ -21,7 +21,7 @@ constexpr int MT = 32;             // base rows per tile (the M side)
 // pushed in two halves of at most 16 entries per query; the per-query buffer of CAP entries is
 // compacted to KP once fewer than 16 entries are free and never holds more than 64 entries, one per
 // lane of the compacting wave.
-template <int KP> struct KnnBuf { static constexpr int CAP = KP == 16 ? 40 : 64, TRIG = CAP - 16; };
+template <int KP> struct KnnBuf { static constexpr int CAP = KP == 16 ? 40 : 44, TRIG = KP == 16 ? 24 : 38; };
 constexpr float INF_F = __builtin_inff();
 
 // Keeps the KP smallest entries of query `qi`'s candidate buffer, ordered by (ranking key, PointId) — the order of
@@ -288,6 +288,11 @@ __global__ void __launch_bounds__(256) knn_split_queries_kernel(const float* __r
 // grid (n_chunks, ceil(nq / MQ)), 256 threads.  KS = 16-dimension steps of the row (padded row = 16 KS floats).  Lane
 // (j, h) of a wave holds, per step, dimensions 16 s + 8 h .. + 8 of query j (B operand, registers) and of tile row j
 // (A operand, read from the tile's two bf16 planes in LDS); the accumulator layout is that of the fp32 32x32 MFMA.
+// Tile buffers of the bf16 kernel: 2 (the next tile is written while this one is contracted, one block barrier per
+// tile) measured the same 12.55 ms per 10k x 1M x 128 batch as 1 (two barriers per tile) and takes 17 KiB more LDS.
+#ifndef KNN_BF16_BUFFERS
+#define KNN_BF16_BUFFERS 1
+#endif
 template <int KS, int KNN_KP>
 __global__ void __launch_bounds__(256) knn_bf16_kernel(GraphView gv, const __bf16* __restrict__ qh, const __bf16* __restrict__ ql, uint32_t nq,
                                                       const float* __restrict__ scale, const float* __restrict__ bias,
@@ -298,11 +303,12 @@ __global__ void __launch_bounds__(256) knn_bf16_kernel(GraphView gv, const __bf1
     constexpr int VPT = CPT / 4;                               // float4 per thread per tile
     static_assert(VPT >= 2 && VPT % 2 == 0, "a loading thread writes 16 bytes per plane at a time");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __bf16* Ah = reinterpret_cast<__bf16*>(smem);                                // MT x LDB high parts
-    __bf16* Al = Ah + MT * LDB;                                                  // MT x LDB remainders
-    float* sc_t = reinterpret_cast<float*>(Al + MT * LDB);                       // MT
-    float* bi_t = sc_t + MT;                                                     // MT
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(bi_t + MT);                      // MQ
+    constexpr int NB = KNN_BF16_BUFFERS;                       // tile buffers
+    __bf16* Ah = reinterpret_cast<__bf16*>(smem);                                // NB x MT x LDB high parts
+    __bf16* Al = Ah + NB * MT * LDB;                                             // NB x MT x LDB remainders
+    float* sc_t = reinterpret_cast<float*>(Al + NB * MT * LDB);                  // NB x MT
+    float* bi_t = sc_t + NB * MT;                                                // NB x MT
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(bi_t + NB * MT);                 // MQ
     uint2* buf = reinterpret_cast<uint2*>(cnt + MQ);                             // MQ x KNN_CAP {key bits, row}
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -338,31 +344,43 @@ __global__ void __launch_bounds__(256) knn_bf16_kernel(GraphView gv, const __bf1
         }
         if (tid < MT) { const uint32_t rr = tile_base + tid; st_sc = rr < r_end ? scale[rr] : 0.f; st_bi = rr < r_end ? bias[rr] : INF_F; }
     };
-    auto stash = [&]() {
+    auto stash = [&](uint32_t ib) {
 #pragma unroll
         for (int v = 0; v < VPT; v += 2) {
             const float x[8] = {stage[v].x, stage[v].y, stage[v].z, stage[v].w, stage[v + 1].x, stage[v + 1].y, stage[v + 1].z, stage[v + 1].w};
             bf16x8 hi, lo;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { __bf16 a, b; bf16_split(x[e], a, b); hi[e] = a; lo[e] = b; }
-            const int at = lrow * LDB + lpart * CPT + v * 4;
+            const int at = (int)ib * MT * LDB + lrow * LDB + lpart * CPT + v * 4;
             *reinterpret_cast<bf16x8*>(Ah + at) = hi;
             *reinterpret_cast<bf16x8*>(Al + at) = lo;
         }
-        if (tid < MT) { sc_t[tid] = st_sc; bi_t[tid] = st_bi; }
+        if (tid < MT) { sc_t[ib * MT + tid] = st_sc; bi_t[ib * MT + tid] = st_bi; }
     };
 
     if (r_begin < r_end) fetch(r_begin);
-    for (uint32_t tb = r_begin; tb < r_end; tb += MT) {
-        __syncthreads();                               // the previous tile has been consumed
-        stash();
+    if (NB == 2) {
+        if (r_begin < r_end) stash(0);
         __syncthreads();
-        if (tb + MT < r_end) fetch(tb + MT);           // in flight during the contraction
+        if (r_begin + MT < r_end) fetch(r_begin + MT);
+    }
+    uint32_t ib = 0;
+    for (uint32_t tb = r_begin; tb < r_end; tb += MT) {
+        if (NB == 1) {
+            __syncthreads();                           // the previous tile has been consumed
+            stash(0);
+            __syncthreads();
+            if (tb + MT < r_end) fetch(tb + MT);       // in flight during the contraction
+        } else {
+            // the other buffer was last read during the previous tile, which every wave left through the barrier below
+            if (tb + MT < r_end) stash(ib ^ 1u);
+            if (tb + 2 * MT < r_end) fetch(tb + 2 * MT);
+        }
         floatx16 acc;
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[v] = 0.f;
-        const __bf16* arh = Ah + j * LDB + 8 * h;
-        const __bf16* arl = Al + j * LDB + 8 * h;
+        const __bf16* arh = Ah + ib * (MT * LDB) + j * LDB + 8 * h;
+        const __bf16* arl = Al + ib * (MT * LDB) + j * LDB + 8 * h;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const bf16x8 ah = *reinterpret_cast<const bf16x8*>(arh + 16 * s);
@@ -375,14 +393,15 @@ __global__ void __launch_bounds__(256) knn_bf16_kernel(GraphView gv, const __bf1
         float key[16];
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            const float4 s4 = *reinterpret_cast<const float4*>(sc_t + g4 * 8 + h * 4);
-            const float4 b4 = *reinterpret_cast<const float4*>(bi_t + g4 * 8 + h * 4);
+            const float4 s4 = *reinterpret_cast<const float4*>(sc_t + ib * MT + g4 * 8 + h * 4);
+            const float4 b4 = *reinterpret_cast<const float4*>(bi_t + ib * MT + g4 * 8 + h * 4);
             key[g4 * 4 + 0] = __builtin_fmaf(acc[g4 * 4 + 0], s4.x, b4.x);
             key[g4 * 4 + 1] = __builtin_fmaf(acc[g4 * 4 + 1], s4.y, b4.y);
             key[g4 * 4 + 2] = __builtin_fmaf(acc[g4 * 4 + 2], s4.z, b4.z);
             key[g4 * 4 + 3] = __builtin_fmaf(acc[g4 * 4 + 3], s4.w, b4.w);
         }
         knn_admit_tile<KNN_KP>(gv, key, tb, q < nq, (uint32_t)wave * 32, cnt, buf, thr, thr_row);
+        if (NB == 2) { __syncthreads(); ib ^= 1u; }    // this tile is consumed, the next one is complete
     }
     // hand over: KNN_KP slots per (query, chunk), NONE32 marks unused entries
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -514,6 +533,127 @@ __global__ void __launch_bounds__(256) knn_mfma_long_kernel(GraphView gv, const 
     }
 }
 
+// Rows longer than 256 floats on the bf16 matrix pipe: knn_mfma_long_kernel's shape (128 rows x 128 queries per block,
+// the row contracted in chunks of 32 floats, accumulators of four 32-row sub-tiles in registers, A slices double
+// buffered in LDS with one block barrier per chunk) with the arithmetic of knn_bf16_kernel: the loader splits the
+// A slice into two bf16 planes, every lane reads its query's two 8-value runs per 16-dimension step from the
+// pre-split planes in global memory (they stay in L2), three MFMAs per step and sub-tile.  One A slice in LDS and two
+// block barriers per chunk, so that two blocks fit a CU (a second slice buffer leaves room for one: 119 against
+// [see DESIGN] ms per 10k x 1M x 768 batch).
+constexpr int KC2 = 32, LDK2 = KC2 + 8;
+template <int KNN_KP>
+__global__ void __launch_bounds__(256) knn_bf16_long_kernel(GraphView gv, const __bf16* __restrict__ qh, const __bf16* __restrict__ ql, uint32_t kq, uint32_t nq,
+                                                           const float* __restrict__ scale, const float* __restrict__ bias,
+                                                           uint32_t* __restrict__ out_slots, uint32_t n_chunks) {
+    constexpr int KNN_CAP = KnnBuf<KNN_KP>::CAP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __bf16* Ah = reinterpret_cast<__bf16*>(smem);                                // LT x LDK2 high parts
+    __bf16* Al = Ah + LT * LDK2;                                                 // LT x LDK2 remainders
+    float* sc_t = reinterpret_cast<float*>(Al + LT * LDK2);                      // LT
+    float* bi_t = sc_t + LT;                                                     // LT
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(bi_t + LT);                      // MQ
+    uint2* buf = reinterpret_cast<uint2*>(cnt + MQ);                             // MQ x KNN_CAP {key bits, row}
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const uint32_t stride = gv.stride;
+    const uint32_t q = blockIdx.y * MQ + wave * 32 + j;
+    const bool qin = q < nq;
+    const __bf16* qhr = qh + (size_t)(qin ? q : 0) * kq + 8 * h;
+    const __bf16* qlr = ql + (size_t)(qin ? q : 0) * kq + 8 * h;
+    const uint32_t nkc = kq / KC2;
+
+    if (tid < MQ) cnt[tid] = 0;
+    float thr = INF_F; uint32_t thr_row = NONE32;  // admission bound of this lane's query: key and row of its KP-th candidate
+    const uint32_t per = (((gv.n + n_chunks - 1) / n_chunks) + LT - 1) / LT * LT;
+    const uint32_t r_begin = blockIdx.x * per, r_end = min(gv.n, r_begin + per);
+    const int lrow = tid >> 1, lhalf = tid & 1;          // loader: thread t brings 16 floats of tile row t / 2
+
+    for (uint32_t tb = r_begin; tb < r_end; tb += LT) {
+        float4 stage[4]; bf16x8 bhq[2], blq[2], bhn[2], bln[2];
+        const uint32_t lr = tb + lrow;
+        const bool lin = lr < r_end;
+        const uint32_t lrp = lin ? lr : r_begin;
+        const float* lsrc = gv.vecs + (size_t)(gv.rowmap ? gv.rowmap[lrp] : lrp) * stride;      // one look-up per tile, ahead of all its loads
+        auto fetch_a = [&](uint32_t kc) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const uint32_t c = kc * KC2 + lhalf * 16 + v * 4;
+                stage[v] = (lin && c < stride) ? *reinterpret_cast<const float4*>(lsrc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto fetch_b = [&](uint32_t kc, bf16x8 (&dh)[2], bf16x8 (&dl)[2]) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                dh[s] = *reinterpret_cast<const bf16x8*>(qhr + kc * KC2 + 16 * s);
+                dl[s] = *reinterpret_cast<const bf16x8*>(qlr + kc * KC2 + 16 * s);
+            }
+        };
+        floatx16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+        __syncthreads();                                   // the previous tile's scale / bias and A slices are consumed
+        if (tid < LT) { const uint32_t rr = tb + tid; sc_t[tid] = rr < r_end ? scale[rr] : 0.f; bi_t[tid] = rr < r_end ? bias[rr] : INF_F; }
+        fetch_a(0); fetch_b(0, bhq, blq);
+        for (uint32_t kc = 0; kc < nkc; ++kc) {
+            constexpr int ab = 0;
+            if (kc > 0) __syncthreads();                   // the previous slice has been consumed (the first follows the tile's barrier)
+#pragma unroll
+            for (int v = 0; v < 4; v += 2) {
+                const float x[8] = {stage[v].x, stage[v].y, stage[v].z, stage[v].w, stage[v + 1].x, stage[v + 1].y, stage[v + 1].z, stage[v + 1].w};
+                bf16x8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { __bf16 a, b; bf16_split(x[e], a, b); hi[e] = a; lo[e] = b; }
+                const int at = ab + lrow * LDK2 + lhalf * 16 + v * 4;
+                *reinterpret_cast<bf16x8*>(Ah + at) = hi;
+                *reinterpret_cast<bf16x8*>(Al + at) = lo;
+            }
+            __syncthreads();
+            if (kc + 1 < nkc) { fetch_a(kc + 1); fetch_b(kc + 1, bhn, bln); }     // in flight during the contraction
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const __bf16* arh = Ah + ab + (t * 32 + j) * LDK2 + 8 * h;
+                const __bf16* arl = Al + ab + (t * 32 + j) * LDK2 + 8 * h;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(arh + 16 * s);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(arl + 16 * s);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bhq[s], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bhq[s], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, blq[s], acc[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { bhq[s] = bhn[s]; blq[s] = bln[s]; }
+        }
+        // epilogue, one 32-row sub-tile at a time: acc[t][v] = q_j . x_i with i = t*32 + (v/4)*8 + h*4 + v%4
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float key[16];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 s4 = *reinterpret_cast<const float4*>(sc_t + t * 32 + g4 * 8 + h * 4);
+                const float4 b4 = *reinterpret_cast<const float4*>(bi_t + t * 32 + g4 * 8 + h * 4);
+                key[g4 * 4 + 0] = __builtin_fmaf(acc[t][g4 * 4 + 0], s4.x, b4.x);
+                key[g4 * 4 + 1] = __builtin_fmaf(acc[t][g4 * 4 + 1], s4.y, b4.y);
+                key[g4 * 4 + 2] = __builtin_fmaf(acc[t][g4 * 4 + 2], s4.z, b4.z);
+                key[g4 * 4 + 3] = __builtin_fmaf(acc[t][g4 * 4 + 3], s4.w, b4.w);
+            }
+            knn_admit_tile<KNN_KP>(gv, key, tb + t * 32, qin, (uint32_t)wave * 32, cnt, buf, thr, thr_row);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int jj = 0; jj < 32; ++jj) {
+        const uint32_t qi = wave * 32 + jj, qg = blockIdx.y * MQ + qi;
+        if (qg >= nq) break;
+        if (cnt[qi] > KNN_KP) { float nt; uint32_t ni; knn_compact<KNN_KP, KNN_CAP>(gv, cnt, buf, qi, nt, ni); }
+        const uint32_t n = cnt[qi];
+        if (lane < KNN_KP) out_slots[((size_t)qg * n_chunks + blockIdx.x) * KNN_KP + lane] = (uint32_t)lane < n ? buf[qi * KNN_CAP + lane].y : NONE32;
+    }
+}
+
 // One wave per query: strict scores of the candidate slots, ranked by (sort_key, id).
 struct TopKList {
     float* key; uint64_t* id; float* raw; uint32_t n, cap;
@@ -617,12 +757,12 @@ uint32_t launch_mfma(const GraphView& g, const float* queries, uint32_t nq, cons
     hipLaunchKernelGGL((knn_mfma_kernel<KH, KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, queries, nq, scale, bias, slots, n_chunks);
     return n_chunks;
 }
-// padded row length of the bf16 planes of the queries (0: the shape runs on the fp32 kernels)
-inline uint32_t knn_bf16_k(uint32_t stride) { return stride <= 64 ? 64u : stride <= 128 ? 128u : stride <= 256 ? 256u : 0u; }
+// padded row length of the bf16 planes of the queries
+inline uint32_t knn_bf16_k(uint32_t stride) { return stride <= 64 ? 64u : stride <= 128 ? 128u : stride <= 256 ? 256u : (stride + 31u) / 32u * 32u; }
 template <int KS, int KP>
 uint32_t launch_bf16(const GraphView& g, const __bf16* qh, const __bf16* ql, uint32_t nq, const float* scale, const float* bias, uint32_t* slots, uint32_t max_chunks, hipStream_t st) {
     constexpr int K = 16 * KS;
-    const size_t lds = (size_t)2 * MT * (K + 8) * 2 + 2 * MT * 4 + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8;
+    const size_t lds = (size_t)KNN_BF16_BUFFERS * ((size_t)2 * MT * (K + 8) * 2 + 2 * MT * 4) + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8;
     const uint32_t n_chunks = pick_chunks(g.n, nq, resident_blocks(knn_bf16_kernel<KS, KP>, lds), max_chunks);
     hipLaunchKernelGGL((knn_bf16_kernel<KS, KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, qh, ql, nq, scale, bias, slots, n_chunks);
     return n_chunks;
@@ -631,7 +771,11 @@ template <int KP>
 uint32_t launch_bf16_any(const GraphView& g, const __bf16* qh, const __bf16* ql, uint32_t nq, const float* scale, const float* bias, uint32_t* slots, uint32_t max_chunks, hipStream_t st) {
     if (g.stride <= 64) return launch_bf16<4, KP>(g, qh, ql, nq, scale, bias, slots, max_chunks, st);
     if (g.stride <= 128) return launch_bf16<8, KP>(g, qh, ql, nq, scale, bias, slots, max_chunks, st);
-    return launch_bf16<16, KP>(g, qh, ql, nq, scale, bias, slots, max_chunks, st);
+    if (g.stride <= 256) return launch_bf16<16, KP>(g, qh, ql, nq, scale, bias, slots, max_chunks, st);
+    const size_t lds = (size_t)2 * LT * LDK2 * 2 + 2 * LT * 4 + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8;
+    const uint32_t n_chunks = pick_chunks(g.n, nq, resident_blocks(knn_bf16_long_kernel<KP>, lds), max_chunks);
+    hipLaunchKernelGGL((knn_bf16_long_kernel<KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, qh, ql, knn_bf16_k(g.stride), nq, scale, bias, slots, n_chunks);
+    return n_chunks;
 }
 template <int KP>
 uint32_t launch_mfma_any(const GraphView& g, const float* queries, uint32_t nq, const float* scale, const float* bias, uint32_t* slots, uint32_t max_chunks, hipStream_t st) {
