@@ -246,6 +246,27 @@ def test_exact_knn_matrix_core_pass_matches_brute_force(ora, vdb, metric, dim):
         assert np.array_equal(ref["sort_key"].view(np.uint32), got["sort_key"].view(np.uint32))
 
 
+@pytest.mark.parametrize("dim", [128, 768])
+def test_exact_knn_far_from_the_origin_matches_brute_force(ora, vdb, dim):
+    """Euclidean rows that share a large common component (every coordinate near 1000, spread 1): |x|^2 is 10^6 times a
+    neighbour's squared distance, so an error relative to the products q_i x_i swamps the gaps between neighbours
+    (without the centring this test fails: VDB_KNN_NO_CENTRE=1).  The matrix-core pass works on rows and queries
+    minus a common centre; ids and bits equal the oracle's brute force."""
+    n, nq, k = (30000, 200, 10) if dim <= 256 else (9000, 100, 10)
+    rng = np.random.default_rng(900 + dim)
+    xs = (1000.0 + rng.standard_normal((n, dim))).astype(np.float32)
+    q = (1000.0 + rng.standard_normal((nq, dim))).astype(np.float32)
+    ids = np.arange(n, dtype=np.uint64) * 2 + 5
+    g = dict(ids=ids, levels=np.zeros(n, np.uint32), vectors=xs, deleted=np.zeros(n, np.uint8), layers=[], entry=int(ids[0]), current_max_level=0)
+    ho = ora.HNSWIndex(2, 16, 64, 16, dim); ho.import_graph(g)
+    ref, refn = ho.exact_knn_batch(q, k)
+    hp = vdb.HNSWIndex(2, 16, 64, 16, dim, arith=vdb.Arith.Fast); hp.import_graph(g)
+    got, gotn = hp.exact_knn_batch(q, k)
+    assert np.array_equal(refn, gotn)
+    assert np.array_equal(ref["id"], got["id"]), np.argwhere(ref["id"] != got["id"])[:5]
+    assert np.array_equal(ref["sort_key"].view(np.uint32), got["sort_key"].view(np.uint32))
+
+
 @pytest.mark.parametrize("metric", [0, 1, 2])
 @pytest.mark.parametrize("case", ["block-of-40", "period-97"])
 def test_exact_knn_many_exact_duplicates_rank_by_id(ora, vdb, metric, case):

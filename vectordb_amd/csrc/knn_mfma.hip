@@ -130,7 +130,25 @@ __device__ __forceinline__ void knn_admit_tile(const GraphView& gv, const float 
 }
 
 // scale / bias turn a dot product into the ranking key: key = dot * scale[row] + bias[row].
-__global__ void __launch_bounds__(256) knn_prepare_kernel(GraphView gv, float* __restrict__ scale, float* __restrict__ bias) {
+// centre[d] = mean of `sample` evenly spaced rows for the Euclidean metric, 0 otherwise (kq entries).  The bf16
+// kernels contract q - centre with x - centre: Euclidean keys do not change with a common shift, but the products
+// they are built from shrink from the rows' distance to the origin to their spread, and the split error with them.
+__global__ void __launch_bounds__(256) knn_centre_kernel(GraphView gv, float* __restrict__ centre, uint32_t kq, uint32_t sample) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= kq) return;
+    float s = 0.f;
+    if (gv.metric == VDB_EUCLIDEAN && d < gv.dim && sample > 0) {
+        const uint32_t step = gv.n / sample;
+        for (uint32_t i = 0; i < sample; ++i) {
+            const uint32_t r = i * step;
+            s += gv.vecs[(size_t)(gv.rowmap ? gv.rowmap[r] : r) * gv.stride + d];
+        }
+        s /= (float)sample;
+    }
+    centre[d] = s;
+}
+
+__global__ void __launch_bounds__(256) knn_prepare_kernel(GraphView gv, const float* __restrict__ centre, float* __restrict__ scale, float* __restrict__ bias) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t r = t >> 3, part = t & 7;                   // eight lanes share a row, 16 bytes each per step
     const bool in = r < gv.n;
@@ -138,7 +156,8 @@ __global__ void __launch_bounds__(256) knn_prepare_kernel(GraphView gv, float* _
     const float4* row = reinterpret_cast<const float4*>(gv.vecs + (size_t)slot * gv.stride);
     float s = 0.f;
     for (uint32_t c = part; c < (gv.stride >> 2); c += 8) {
-        const float4 v = row[c];
+        float4 v = row[c];
+        if (centre) { const float4 m = reinterpret_cast<const float4*>(centre)[c]; v.x -= m.x; v.y -= m.y; v.z -= m.z; v.w -= m.w; }
         s = __builtin_fmaf(v.x, v.x, s); s = __builtin_fmaf(v.y, v.y, s); s = __builtin_fmaf(v.z, v.z, s); s = __builtin_fmaf(v.w, v.w, s);
     }
     s = group_sum<8>(s);
@@ -274,13 +293,13 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void bf16_split(float x, __bf16& h, __bf16& l) { h = (__bf16)x; l = (__bf16)(x - (float)h); }
 
-// queries -> two planes (high parts, remainders) of nq x kq bf16, zero beyond dim
-__global__ void __launch_bounds__(256) knn_split_queries_kernel(const float* __restrict__ queries, uint32_t nq, uint32_t dim, uint32_t kq,
+// queries minus the centre -> two planes (high parts, remainders) of nq x kq bf16, zero beyond dim
+__global__ void __launch_bounds__(256) knn_split_queries_kernel(const float* __restrict__ queries, const float* __restrict__ centre, uint32_t nq, uint32_t dim, uint32_t kq,
                                                                __bf16* __restrict__ qh, __bf16* __restrict__ ql) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)nq * kq) return;
     const uint32_t q = (uint32_t)(i / kq), d = (uint32_t)(i % kq);
-    const float x = d < dim ? queries[(size_t)q * dim + d] : 0.f;
+    const float x = d < dim ? queries[(size_t)q * dim + d] - centre[d] : 0.f;
     __bf16 h, l; bf16_split(x, h, l);
     qh[i] = h; ql[i] = l;
 }
@@ -295,7 +314,7 @@ __global__ void __launch_bounds__(256) knn_split_queries_kernel(const float* __r
 #endif
 template <int KS, int KNN_KP>
 __global__ void __launch_bounds__(256) knn_bf16_kernel(GraphView gv, const __bf16* __restrict__ qh, const __bf16* __restrict__ ql, uint32_t nq,
-                                                      const float* __restrict__ scale, const float* __restrict__ bias,
+                                                      const float* __restrict__ centre, const float* __restrict__ scale, const float* __restrict__ bias,
                                                       uint32_t* __restrict__ out_slots, uint32_t n_chunks) {
     constexpr int K = 16 * KS, LDB = K + 8;                    // bf16 per tile row, padded by 16 bytes: conflict-free 16-byte reads
     constexpr int KNN_CAP = KnnBuf<KNN_KP>::CAP;
@@ -330,7 +349,9 @@ __global__ void __launch_bounds__(256) knn_bf16_kernel(GraphView gv, const __bf1
     const uint32_t r_begin = blockIdx.x * per, r_end = min(gv.n, r_begin + per);
     // loader: thread t brings columns [part * CPT, + CPT) of tile row t / 8
     const int lrow = tid >> 3, lpart = tid & 7;
-    float4 stage[VPT];
+    float4 stage[VPT], mid[VPT];                               // mid: the centre's values of this thread's columns
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) mid[v] = *reinterpret_cast<const float4*>(centre + lpart * CPT + v * 4);
     float st_sc = 0.f, st_bi = INF_F;
     auto fetch = [&](uint32_t tile_base) {
         const uint32_t r = tile_base + lrow;
@@ -347,7 +368,8 @@ __global__ void __launch_bounds__(256) knn_bf16_kernel(GraphView gv, const __bf1
     auto stash = [&](uint32_t ib) {
 #pragma unroll
         for (int v = 0; v < VPT; v += 2) {
-            const float x[8] = {stage[v].x, stage[v].y, stage[v].z, stage[v].w, stage[v + 1].x, stage[v + 1].y, stage[v + 1].z, stage[v + 1].w};
+            const float x[8] = {stage[v].x - mid[v].x, stage[v].y - mid[v].y, stage[v].z - mid[v].z, stage[v].w - mid[v].w,
+                                stage[v + 1].x - mid[v + 1].x, stage[v + 1].y - mid[v + 1].y, stage[v + 1].z - mid[v + 1].z, stage[v + 1].w - mid[v + 1].w};
             bf16x8 hi, lo;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { __bf16 a, b; bf16_split(x[e], a, b); hi[e] = a; lo[e] = b; }
@@ -543,7 +565,7 @@ __global__ void __launch_bounds__(256) knn_mfma_long_kernel(GraphView gv, const 
 constexpr int KC2 = 32, LDK2 = KC2 + 8;
 template <int KNN_KP>
 __global__ void __launch_bounds__(256) knn_bf16_long_kernel(GraphView gv, const __bf16* __restrict__ qh, const __bf16* __restrict__ ql, uint32_t kq, uint32_t nq,
-                                                           const float* __restrict__ scale, const float* __restrict__ bias,
+                                                           const float* __restrict__ centre, const float* __restrict__ scale, const float* __restrict__ bias,
                                                            uint32_t* __restrict__ out_slots, uint32_t n_chunks) {
     constexpr int KNN_CAP = KnnBuf<KNN_KP>::CAP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -570,7 +592,7 @@ __global__ void __launch_bounds__(256) knn_bf16_long_kernel(GraphView gv, const 
     const int lrow = tid >> 1, lhalf = tid & 1;          // loader: thread t brings 16 floats of tile row t / 2
 
     for (uint32_t tb = r_begin; tb < r_end; tb += LT) {
-        float4 stage[4]; bf16x8 bhq[2], blq[2], bhn[2], bln[2];
+        float4 stage[4], mid[4]; bf16x8 bhq[2], blq[2], bhn[2], bln[2];
         const uint32_t lr = tb + lrow;
         const bool lin = lr < r_end;
         const uint32_t lrp = lin ? lr : r_begin;
@@ -580,6 +602,7 @@ __global__ void __launch_bounds__(256) knn_bf16_long_kernel(GraphView gv, const 
             for (int v = 0; v < 4; ++v) {
                 const uint32_t c = kc * KC2 + lhalf * 16 + v * 4;
                 stage[v] = (lin && c < stride) ? *reinterpret_cast<const float4*>(lsrc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                mid[v] = *reinterpret_cast<const float4*>(centre + c);
             }
         };
         auto fetch_b = [&](uint32_t kc, bf16x8 (&dh)[2], bf16x8 (&dl)[2]) {
@@ -602,7 +625,8 @@ __global__ void __launch_bounds__(256) knn_bf16_long_kernel(GraphView gv, const 
             if (kc > 0) __syncthreads();                   // the previous slice has been consumed (the first follows the tile's barrier)
 #pragma unroll
             for (int v = 0; v < 4; v += 2) {
-                const float x[8] = {stage[v].x, stage[v].y, stage[v].z, stage[v].w, stage[v + 1].x, stage[v + 1].y, stage[v + 1].z, stage[v + 1].w};
+                const float x[8] = {stage[v].x - mid[v].x, stage[v].y - mid[v].y, stage[v].z - mid[v].z, stage[v].w - mid[v].w,
+                                    stage[v + 1].x - mid[v + 1].x, stage[v + 1].y - mid[v + 1].y, stage[v + 1].z - mid[v + 1].z, stage[v + 1].w - mid[v + 1].w};
                 bf16x8 hi, lo;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { __bf16 a, b; bf16_split(x[e], a, b); hi[e] = a; lo[e] = b; }
@@ -760,21 +784,21 @@ uint32_t launch_mfma(const GraphView& g, const float* queries, uint32_t nq, cons
 // padded row length of the bf16 planes of the queries
 inline uint32_t knn_bf16_k(uint32_t stride) { return stride <= 64 ? 64u : stride <= 128 ? 128u : stride <= 256 ? 256u : (stride + 31u) / 32u * 32u; }
 template <int KS, int KP>
-uint32_t launch_bf16(const GraphView& g, const __bf16* qh, const __bf16* ql, uint32_t nq, const float* scale, const float* bias, uint32_t* slots, uint32_t max_chunks, hipStream_t st) {
+uint32_t launch_bf16(const GraphView& g, const __bf16* qh, const __bf16* ql, uint32_t nq, const float* centre, const float* scale, const float* bias, uint32_t* slots, uint32_t max_chunks, hipStream_t st) {
     constexpr int K = 16 * KS;
     const size_t lds = (size_t)KNN_BF16_BUFFERS * ((size_t)2 * MT * (K + 8) * 2 + 2 * MT * 4) + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8;
     const uint32_t n_chunks = pick_chunks(g.n, nq, resident_blocks(knn_bf16_kernel<KS, KP>, lds), max_chunks);
-    hipLaunchKernelGGL((knn_bf16_kernel<KS, KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, qh, ql, nq, scale, bias, slots, n_chunks);
+    hipLaunchKernelGGL((knn_bf16_kernel<KS, KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, qh, ql, nq, centre, scale, bias, slots, n_chunks);
     return n_chunks;
 }
 template <int KP>
-uint32_t launch_bf16_any(const GraphView& g, const __bf16* qh, const __bf16* ql, uint32_t nq, const float* scale, const float* bias, uint32_t* slots, uint32_t max_chunks, hipStream_t st) {
-    if (g.stride <= 64) return launch_bf16<4, KP>(g, qh, ql, nq, scale, bias, slots, max_chunks, st);
-    if (g.stride <= 128) return launch_bf16<8, KP>(g, qh, ql, nq, scale, bias, slots, max_chunks, st);
-    if (g.stride <= 256) return launch_bf16<16, KP>(g, qh, ql, nq, scale, bias, slots, max_chunks, st);
+uint32_t launch_bf16_any(const GraphView& g, const __bf16* qh, const __bf16* ql, uint32_t nq, const float* centre, const float* scale, const float* bias, uint32_t* slots, uint32_t max_chunks, hipStream_t st) {
+    if (g.stride <= 64) return launch_bf16<4, KP>(g, qh, ql, nq, centre, scale, bias, slots, max_chunks, st);
+    if (g.stride <= 128) return launch_bf16<8, KP>(g, qh, ql, nq, centre, scale, bias, slots, max_chunks, st);
+    if (g.stride <= 256) return launch_bf16<16, KP>(g, qh, ql, nq, centre, scale, bias, slots, max_chunks, st);
     const size_t lds = (size_t)2 * LT * LDK2 * 2 + 2 * LT * 4 + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8;
     const uint32_t n_chunks = pick_chunks(g.n, nq, resident_blocks(knn_bf16_long_kernel<KP>, lds), max_chunks);
-    hipLaunchKernelGGL((knn_bf16_long_kernel<KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, qh, ql, knn_bf16_k(g.stride), nq, scale, bias, slots, n_chunks);
+    hipLaunchKernelGGL((knn_bf16_long_kernel<KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, qh, ql, knn_bf16_k(g.stride), nq, centre, scale, bias, slots, n_chunks);
     return n_chunks;
 }
 template <int KP>
@@ -793,29 +817,36 @@ inline uint32_t knn_kp(uint32_t top_k) { return top_k + 4 <= 16 ? 16u : 32u; }
 
 bool knn_mfma_supported(const GraphView& g, uint32_t top_k) { return top_k >= 1 && top_k + 4 <= 32 && g.stride <= MAX_DIM && g.n > 0; }
 // room for the largest chunk count and candidate width the launch may pick
-// words of the fixed part of the scratch: row scale and bias (rounded up to 16 bytes) and the two bf16 planes of the queries
-static size_t knn_fixed_words(uint32_t n, uint32_t nq, uint32_t stride) { return ((2 * (size_t)n + 3) & ~size_t(3)) + (size_t)nq * knn_bf16_k(stride); }
+// words of the fixed part of the scratch: the centre, row scale and bias (rounded up to 16 bytes) and the two bf16 planes of the queries
+static size_t knn_fixed_words(uint32_t n, uint32_t nq, uint32_t stride) { return knn_bf16_k(stride) + ((2 * (size_t)n + 3) & ~size_t(3)) + (size_t)nq * knn_bf16_k(stride); }
 size_t knn_mfma_scratch_words(uint32_t n, uint32_t nq, uint32_t stride) {
     return knn_fixed_words(n, nq, stride) + (size_t)nq * std::max<uint32_t>(1, std::min<uint32_t>(64, n / 4096)) * 32;
 }
 
-// scratch: [scale n][bias n][query planes: 2 x nq x K bf16][candidate slots: nq x chunks x KP], chunks <= max_chunks
+// scratch: [centre K][scale n][bias n][query planes: 2 x nq x K bf16][candidate slots: nq x chunks x KP], chunks <= max_chunks
 static void run_exact_knn_mfma(const GraphView& g, const float* queries, uint32_t nq, uint32_t top_k, vdb_scored_point* out, uint32_t* out_n,
                                uint32_t* scratch, uint32_t max_chunks, hipStream_t st) {
-    float* scale = reinterpret_cast<float*>(scratch); float* bias = scale + g.n;
-    const uint32_t kq = std::getenv("VDB_KNN_FP32") ? 0u : knn_bf16_k(g.stride);
-    __bf16* qh = reinterpret_cast<__bf16*>(scratch + ((2 * (size_t)g.n + 3) & ~size_t(3))); __bf16* ql = qh + (size_t)nq * knn_bf16_k(g.stride);
+    const uint32_t kpad = knn_bf16_k(g.stride);
+    const bool bf16 = !std::getenv("VDB_KNN_FP32");            // diagnostic: the fp32 MFMA kernels the bf16 ones are measured against
+    float* centre = reinterpret_cast<float*>(scratch);
+    float* scale = centre + kpad; float* bias = scale + g.n;
+    __bf16* qh = reinterpret_cast<__bf16*>(scratch + kpad + ((2 * (size_t)g.n + 3) & ~size_t(3))); __bf16* ql = qh + (size_t)nq * kpad;
     uint32_t* slots = scratch + knn_fixed_words(g.n, nq, g.stride);
-    hipLaunchKernelGGL(knn_prepare_kernel, dim3((g.n + 31) / 32), dim3(256), 0, st, g, scale, bias);
+    if (bf16) {
+        hipLaunchKernelGGL(knn_centre_kernel, dim3((kpad + 255) / 256), dim3(256), 0, st, g, centre, kpad,
+                           std::getenv("VDB_KNN_NO_CENTRE") ? 0u : std::min<uint32_t>(g.n, 2048u));   // (diagnostic: what the centring buys)
+        VDB_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(knn_prepare_kernel, dim3((g.n + 31) / 32), dim3(256), 0, st, g, bf16 ? centre : nullptr, scale, bias);
     VDB_HIP(hipGetLastError());
     const uint32_t kp = knn_kp(top_k);
     uint32_t n_chunks;
-    if (kq) {
-        const size_t cells = (size_t)nq * kq;
-        hipLaunchKernelGGL(knn_split_queries_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, queries, nq, g.dim, kq, qh, ql);
+    if (bf16) {
+        const size_t cells = (size_t)nq * kpad;
+        hipLaunchKernelGGL(knn_split_queries_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, queries, centre, nq, g.dim, kpad, qh, ql);
         VDB_HIP(hipGetLastError());
-        n_chunks = kp == 16 ? launch_bf16_any<16>(g, qh, ql, nq, scale, bias, slots, max_chunks, st)
-                            : launch_bf16_any<32>(g, qh, ql, nq, scale, bias, slots, max_chunks, st);
+        n_chunks = kp == 16 ? launch_bf16_any<16>(g, qh, ql, nq, centre, scale, bias, slots, max_chunks, st)
+                            : launch_bf16_any<32>(g, qh, ql, nq, centre, scale, bias, slots, max_chunks, st);
     } else {
         n_chunks = kp == 16 ? launch_mfma_any<16>(g, queries, nq, scale, bias, slots, max_chunks, st)
                             : launch_mfma_any<32>(g, queries, nq, scale, bias, slots, max_chunks, st);
