@@ -224,8 +224,8 @@ vdb_status vdb_index_exact_knn_batch_dev(const vdb_index* x, const float* d_quer
 /* The same as vdb_index_exact_knn_batch_dev with NO allocation (no counterpart in the reference; for callers that
  * cannot allocate: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  The
  * candidate pass works in a 16 MiB scratch array that is part of the library's code object (one copy per GPU, held
- * until the process ends).  Limits: FAST index, 1 <= top_k <= 28, 2 * rows + nq * (top_k <= 12 ? 16 : 32) <= 4 Mi
- * words, and no edit pending (after inserts or mark_deleted call vdb_index_sync_device first); anything else is
+ * until the process ends).  Limits: FAST index, 1 <= top_k <= 28, K + 2 * rows + nq * (K + (top_k <= 12 ? 16 : 32)) <= 4 Mi
+ * words with K the padded row length (64, 128, 256, else the next multiple of 32), and no edit pending (after inserts or mark_deleted call vdb_index_sync_device first); anything else is
  * VDB_ERR_ARGUMENT and nothing is launched.  Every call on one GPU shares the scratch array: calls that overlap on
  * one GPU (any index, any stream) race, so order them on one stream or with events. */
 vdb_status vdb_index_exact_knn_batch_dev_noalloc(const vdb_index* x, const float* d_queries, size_t nq, size_t top_k,

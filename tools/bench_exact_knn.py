@@ -1,6 +1,7 @@
 """Times the exact k-NN path (10k queries x 1M x 128 by default) on one GPU: device-resident queries and
 results, HIP events on the launch stream.  Prints one JSON line with seconds per batch and the
-TFLOP/s of the contraction (2*Q*N*D flop) against the fp32 MFMA peak."""
+TFLOP/s of the contraction in fp32 terms (2*Q*N*D flop) against the fp32 MFMA peak; the candidate pass itself runs
+three bf16 MFMAs per product (VDB_KNN_FP32=1: the fp32 MFMA kernels), so `frac` can exceed 1."""
 import argparse, json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -36,4 +37,5 @@ e1.record(st); st.synchronize()
 sec = e0.elapsed_time(e1) / 1e3 / args.steps
 tf = 2.0 * Q * N * D / sec / 1e12
 print(json.dumps({"workload": f"exact k-NN {Q} x {N} x {D}, top-{K}, metric {args.metric}", "seconds_per_batch": sec,
-                  "tflops": tf, "peak_tflops_fp32_mfma": 157.3, "frac": tf / 157.3}))
+                  "tflops": tf, "peak_tflops_fp32_mfma": 157.3, "frac": tf / 157.3,
+                  "candidate_pass": "fp32 MFMA" if os.environ.get("VDB_KNN_FP32") else "bf16 split, 3 MFMAs per product", "bf16_tflops_issued": None if os.environ.get("VDB_KNN_FP32") else 3 * tf, "peak_tflops_bf16_mfma": 2500.0}))
