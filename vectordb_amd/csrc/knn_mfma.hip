@@ -304,21 +304,26 @@ __global__ void __launch_bounds__(256) knn_split_queries_kernel(const float* __r
     qh[i] = h; ql[i] = l;
 }
 
-// grid (n_chunks, ceil(nq / MQ)), 256 threads.  KS = 16-dimension steps of the row (padded row = 16 KS floats).  Lane
+// grid (n_chunks, ceil(nq / (32 WPB))), WPB waves per block.  KS = 16-dimension steps of the row (padded row = 16 KS floats).  Lane
 // (j, h) of a wave holds, per step, dimensions 16 s + 8 h .. + 8 of query j (B operand, registers) and of tile row j
 // (A operand, read from the tile's two bf16 planes in LDS); the accumulator layout is that of the fp32 32x32 MFMA.
+// Waves per block of the bf16 kernel (32 queries each): eight share a tile's loads, split and barriers; measured per
+// 10k x 1M batch — 128-float rows: 14.2 ms with eight, 13.9 with four (top-20: 19.3 against 16.6); 256-float rows: 24.4
+// against 37 ms (four waves with 64 query registers each leave room for one wave per SIMD).  Eight for 256, four below.
 // Tile buffers of the bf16 kernel: 2 (the next tile is written while this one is contracted, one block barrier per
 // tile) measured the same 12.55 ms per 10k x 1M x 128 batch as 1 (two barriers per tile) and takes 17 KiB more LDS.
 #ifndef KNN_BF16_BUFFERS
 #define KNN_BF16_BUFFERS 1
 #endif
-template <int KS, int KNN_KP>
-__global__ void __launch_bounds__(256) knn_bf16_kernel(GraphView gv, const __bf16* __restrict__ qh, const __bf16* __restrict__ ql, uint32_t nq,
+template <int KS, int KNN_KP, int WPB>
+__global__ void __launch_bounds__(64 * WPB) knn_bf16_kernel(GraphView gv, const __bf16* __restrict__ qh, const __bf16* __restrict__ ql, uint32_t nq,
                                                       const float* __restrict__ centre, const float* __restrict__ scale, const float* __restrict__ bias,
                                                       uint32_t* __restrict__ out_slots, uint32_t n_chunks) {
     constexpr int K = 16 * KS, LDB = K + 8;                    // bf16 per tile row, padded by 16 bytes: conflict-free 16-byte reads
     constexpr int KNN_CAP = KnnBuf<KNN_KP>::CAP;
-    constexpr int CPT = K / 8;                                 // floats per loading thread: eight threads per tile row
+    constexpr int MQB = 32 * WPB;                              // queries per block: 32 per wave
+    constexpr int TPR = 2 * WPB;                               // loading threads per tile row (all threads load)
+    constexpr int CPT = K / TPR;                               // floats per loading thread
     constexpr int VPT = CPT / 4;                               // float4 per thread per tile
     static_assert(VPT >= 2 && VPT % 2 == 0, "a loading thread writes 16 bytes per plane at a time");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -327,13 +332,13 @@ __global__ void __launch_bounds__(256) knn_bf16_kernel(GraphView gv, const __bf1
     __bf16* Al = Ah + NB * MT * LDB;                                             // NB x MT x LDB remainders
     float* sc_t = reinterpret_cast<float*>(Al + NB * MT * LDB);                  // NB x MT
     float* bi_t = sc_t + NB * MT;                                                // NB x MT
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(bi_t + NB * MT);                 // MQ
-    uint2* buf = reinterpret_cast<uint2*>(cnt + MQ);                             // MQ x KNN_CAP {key bits, row}
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(bi_t + NB * MT);                 // MQB
+    uint2* buf = reinterpret_cast<uint2*>(cnt + MQB);                            // MQB x KNN_CAP {key bits, row}
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const uint32_t stride = gv.stride;
-    const uint32_t q = blockIdx.y * MQ + wave * 32 + j;        // this lane's query (two lanes per query)
+    const uint32_t q = blockIdx.y * MQB + wave * 32 + j;       // this lane's query (two lanes per query)
 
     bf16x8 bh[KS], bl[KS];                                     // B operand: the whole query stays in registers
 #pragma unroll
@@ -342,13 +347,13 @@ __global__ void __launch_bounds__(256) knn_bf16_kernel(GraphView gv, const __bf1
         bh[s] = *reinterpret_cast<const bf16x8*>(qh + off);
         bl[s] = *reinterpret_cast<const bf16x8*>(ql + off);
     }
-    if (tid < MQ) cnt[tid] = 0;
+    if (tid < MQB) cnt[tid] = 0;
     float thr = INF_F; uint32_t thr_row = NONE32;  // admission bound of this lane's query: key and row of its KP-th candidate
 
     const uint32_t per = (((gv.n + n_chunks - 1) / n_chunks) + MT - 1) / MT * MT;
     const uint32_t r_begin = blockIdx.x * per, r_end = min(gv.n, r_begin + per);
-    // loader: thread t brings columns [part * CPT, + CPT) of tile row t / 8
-    const int lrow = tid >> 3, lpart = tid & 7;
+    // loader: thread t brings columns [part * CPT, + CPT) of tile row t / TPR
+    const int lrow = tid / TPR, lpart = tid % TPR;
     float4 stage[VPT], mid[VPT];                               // mid: the centre's values of this thread's columns
 #pragma unroll
     for (int v = 0; v < VPT; ++v) mid[v] = *reinterpret_cast<const float4*>(centre + lpart * CPT + v * 4);
@@ -428,7 +433,7 @@ __global__ void __launch_bounds__(256) knn_bf16_kernel(GraphView gv, const __bf1
     // hand over: KNN_KP slots per (query, chunk), NONE32 marks unused entries
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     for (int jj = 0; jj < 32; ++jj) {
-        const uint32_t qi = wave * 32 + jj, qg = blockIdx.y * MQ + qi;
+        const uint32_t qi = wave * 32 + jj, qg = blockIdx.y * MQB + qi;
         if (qg >= nq) break;
         if (cnt[qi] > KNN_KP) { float nt; uint32_t ni; knn_compact<KNN_KP, KNN_CAP>(gv, cnt, buf, qi, nt, ni); }
         const uint32_t n = cnt[qi];
@@ -753,8 +758,8 @@ __global__ void __launch_bounds__(64) knn_rerank_kernel(GraphView gv, const floa
 
 // Blocks of one launch do equal work, so the launch lasts ceil(blocks / resident blocks) rounds: the base set is cut
 // into the number of chunks that wastes least of the last round (more chunks also mean more candidates to re-rank).
-inline uint32_t pick_chunks(uint32_t n, uint32_t nq, uint32_t resident, uint32_t max_chunks) {
-    const uint32_t qblocks = (nq + MQ - 1) / MQ;
+inline uint32_t pick_chunks(uint32_t n, uint32_t nq, uint32_t qblock, uint32_t resident, uint32_t max_chunks) {
+    const uint32_t qblocks = (nq + qblock - 1) / qblock;
     const uint32_t cmax = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(64, max_chunks), n / 4096));
     uint32_t best = 1; double best_cost = 1e30;
     for (uint32_t c = 1; c <= cmax; ++c) {
@@ -777,27 +782,31 @@ uint32_t launch_mfma(const GraphView& g, const float* queries, uint32_t nq, cons
     constexpr int K = 2 * KH;
     constexpr int ROWS = MT;
     const size_t lds = ((size_t)ROWS * (K + 4) * 4 + 2 * ROWS * 4) + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8;
-    const uint32_t n_chunks = pick_chunks(g.n, nq, resident_blocks(knn_mfma_kernel<KH, KP>, lds), max_chunks);
+    const uint32_t n_chunks = pick_chunks(g.n, nq, MQ, resident_blocks(knn_mfma_kernel<KH, KP>, lds), max_chunks);
     hipLaunchKernelGGL((knn_mfma_kernel<KH, KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, queries, nq, scale, bias, slots, n_chunks);
     return n_chunks;
 }
 // padded row length of the bf16 planes of the queries
 inline uint32_t knn_bf16_k(uint32_t stride) { return stride <= 64 ? 64u : stride <= 128 ? 128u : stride <= 256 ? 256u : (stride + 31u) / 32u * 32u; }
-template <int KS, int KP>
+template <int KS, int KP, int WPB>
 uint32_t launch_bf16(const GraphView& g, const __bf16* qh, const __bf16* ql, uint32_t nq, const float* centre, const float* scale, const float* bias, uint32_t* slots, uint32_t max_chunks, hipStream_t st) {
-    constexpr int K = 16 * KS;
-    const size_t lds = (size_t)KNN_BF16_BUFFERS * ((size_t)2 * MT * (K + 8) * 2 + 2 * MT * 4) + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8;
-    const uint32_t n_chunks = pick_chunks(g.n, nq, resident_blocks(knn_bf16_kernel<KS, KP>, lds), max_chunks);
-    hipLaunchKernelGGL((knn_bf16_kernel<KS, KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, qh, ql, nq, centre, scale, bias, slots, n_chunks);
+    constexpr int K = 16 * KS, MQB = 32 * WPB;
+    const size_t lds = (size_t)KNN_BF16_BUFFERS * ((size_t)2 * MT * (K + 8) * 2 + 2 * MT * 4) + MQB * 4 + (size_t)MQB * KnnBuf<KP>::CAP * 8;
+    int dev = 0, cus = 256, per_cu = 1;
+    VDB_HIP(hipGetDevice(&dev));
+    VDB_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    VDB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, knn_bf16_kernel<KS, KP, WPB>, 64 * WPB, lds));
+    const uint32_t n_chunks = pick_chunks(g.n, nq, MQB, (uint32_t)std::max(1, cus) * (uint32_t)std::max(1, per_cu), max_chunks);
+    hipLaunchKernelGGL((knn_bf16_kernel<KS, KP, WPB>), dim3(n_chunks, (nq + MQB - 1) / MQB), dim3(64 * WPB), lds, st, g, qh, ql, nq, centre, scale, bias, slots, n_chunks);
     return n_chunks;
 }
 template <int KP>
 uint32_t launch_bf16_any(const GraphView& g, const __bf16* qh, const __bf16* ql, uint32_t nq, const float* centre, const float* scale, const float* bias, uint32_t* slots, uint32_t max_chunks, hipStream_t st) {
-    if (g.stride <= 64) return launch_bf16<4, KP>(g, qh, ql, nq, centre, scale, bias, slots, max_chunks, st);
-    if (g.stride <= 128) return launch_bf16<8, KP>(g, qh, ql, nq, centre, scale, bias, slots, max_chunks, st);
-    if (g.stride <= 256) return launch_bf16<16, KP>(g, qh, ql, nq, centre, scale, bias, slots, max_chunks, st);
+    if (g.stride <= 64) return launch_bf16<4, KP, 4>(g, qh, ql, nq, centre, scale, bias, slots, max_chunks, st);
+    if (g.stride <= 128) return launch_bf16<8, KP, 4>(g, qh, ql, nq, centre, scale, bias, slots, max_chunks, st);
+    if (g.stride <= 256) return launch_bf16<16, KP, 8>(g, qh, ql, nq, centre, scale, bias, slots, max_chunks, st);
     const size_t lds = (size_t)2 * LT * LDK2 * 2 + 2 * LT * 4 + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8;
-    const uint32_t n_chunks = pick_chunks(g.n, nq, resident_blocks(knn_bf16_long_kernel<KP>, lds), max_chunks);
+    const uint32_t n_chunks = pick_chunks(g.n, nq, MQ, resident_blocks(knn_bf16_long_kernel<KP>, lds), max_chunks);
     hipLaunchKernelGGL((knn_bf16_long_kernel<KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, qh, ql, knn_bf16_k(g.stride), nq, centre, scale, bias, slots, n_chunks);
     return n_chunks;
 }
@@ -807,7 +816,7 @@ uint32_t launch_mfma_any(const GraphView& g, const float* queries, uint32_t nq, 
     if (g.stride <= 128) return launch_mfma<64, KP>(g, queries, nq, scale, bias, slots, max_chunks, st);
     if (g.stride <= 256) return launch_mfma<128, KP>(g, queries, nq, scale, bias, slots, max_chunks, st);
     const size_t lds = (size_t)2 * LT * LDK * 4 + 2 * LT * 4 + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8;
-    const uint32_t n_chunks = pick_chunks(g.n, nq, resident_blocks(knn_mfma_long_kernel<KP>, lds), max_chunks);
+    const uint32_t n_chunks = pick_chunks(g.n, nq, MQ, resident_blocks(knn_mfma_long_kernel<KP>, lds), max_chunks);
     hipLaunchKernelGGL((knn_mfma_long_kernel<KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, queries, nq, scale, bias, slots, n_chunks);
     return n_chunks;
 }
