@@ -565,11 +565,11 @@ __global__ void __launch_bounds__(256) knn_mfma_long_kernel(GraphView gv, const 
 // buffered in LDS with one block barrier per chunk) with the arithmetic of knn_bf16_kernel: the loader splits the
 // A slice into two bf16 planes, every lane reads its query's two 8-value runs per 16-dimension step from the
 // pre-split planes in global memory (they stay in L2), three MFMAs per step and sub-tile.  One A slice in LDS and two
-// block barriers per chunk, so that two blocks fit a CU (a second slice buffer leaves room for one: 119 against
-// [see DESIGN] ms per 10k x 1M x 768 batch).
+// block barriers per chunk, so that two blocks fit a CU (a second slice buffer leaves room for one: 119 against 107 ms
+// per 10k x 1M x 768 batch); the centre sits in LDS.
 constexpr int KC2 = 32, LDK2 = KC2 + 8;
 template <int KNN_KP>
-__global__ void __launch_bounds__(256) knn_bf16_long_kernel(GraphView gv, const __bf16* __restrict__ qh, const __bf16* __restrict__ ql, uint32_t kq, uint32_t nq,
+__global__ void __launch_bounds__(256, 2) knn_bf16_long_kernel(GraphView gv, const __bf16* __restrict__ qh, const __bf16* __restrict__ ql, uint32_t kq, uint32_t nq,
                                                            const float* __restrict__ centre, const float* __restrict__ scale, const float* __restrict__ bias,
                                                            uint32_t* __restrict__ out_slots, uint32_t n_chunks) {
     constexpr int KNN_CAP = KnnBuf<KNN_KP>::CAP;
@@ -580,12 +580,14 @@ __global__ void __launch_bounds__(256) knn_bf16_long_kernel(GraphView gv, const 
     float* bi_t = sc_t + LT;                                                     // LT
     uint32_t* cnt = reinterpret_cast<uint32_t*>(bi_t + LT);                      // MQ
     uint2* buf = reinterpret_cast<uint2*>(cnt + MQ);                             // MQ x KNN_CAP {key bits, row}
+    float* mid_l = reinterpret_cast<float*>(buf + MQ * KNN_CAP);                 // kq: the centre
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const uint32_t stride = gv.stride;
     const uint32_t q = blockIdx.y * MQ + wave * 32 + j;
     const bool qin = q < nq;
+    for (uint32_t i = tid; i < kq; i += 256) mid_l[i] = centre[i];
     const __bf16* qhr = qh + (size_t)(qin ? q : 0) * kq + 8 * h;
     const __bf16* qlr = ql + (size_t)(qin ? q : 0) * kq + 8 * h;
     const uint32_t nkc = kq / KC2;
@@ -597,17 +599,18 @@ __global__ void __launch_bounds__(256) knn_bf16_long_kernel(GraphView gv, const 
     const int lrow = tid >> 1, lhalf = tid & 1;          // loader: thread t brings 16 floats of tile row t / 2
 
     for (uint32_t tb = r_begin; tb < r_end; tb += LT) {
-        float4 stage[4], mid[4]; bf16x8 bhq[2], blq[2], bhn[2], bln[2];
+        // the A slices of the next two chunks are in flight (st0: even chunks, st1: odd ones) while a chunk is contracted:
+        // with one chunk ahead an iteration lasts as long as a memory round trip, whatever it computes
+        float4 st0[4], st1[4]; bf16x8 bhq[2], blq[2], bhn[2], bln[2];
         const uint32_t lr = tb + lrow;
         const bool lin = lr < r_end;
         const uint32_t lrp = lin ? lr : r_begin;
         const float* lsrc = gv.vecs + (size_t)(gv.rowmap ? gv.rowmap[lrp] : lrp) * stride;      // one look-up per tile, ahead of all its loads
-        auto fetch_a = [&](uint32_t kc) {
+        auto fetch_a = [&](uint32_t kc, float4 (&st)[4]) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const uint32_t c = kc * KC2 + lhalf * 16 + v * 4;
-                stage[v] = (lin && c < stride) ? *reinterpret_cast<const float4*>(lsrc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-                mid[v] = *reinterpret_cast<const float4*>(centre + c);
+                st[v] = (lin && c < stride) ? *reinterpret_cast<const float4*>(lsrc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         };
         auto fetch_b = [&](uint32_t kc, bf16x8 (&dh)[2], bf16x8 (&dl)[2]) {
@@ -622,29 +625,28 @@ __global__ void __launch_bounds__(256) knn_bf16_long_kernel(GraphView gv, const 
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
-        __syncthreads();                                   // the previous tile's scale / bias and A slices are consumed
-        if (tid < LT) { const uint32_t rr = tb + tid; sc_t[tid] = rr < r_end ? scale[rr] : 0.f; bi_t[tid] = rr < r_end ? bias[rr] : INF_F; }
-        fetch_a(0); fetch_b(0, bhq, blq);
-        for (uint32_t kc = 0; kc < nkc; ++kc) {
-            constexpr int ab = 0;
+        auto chunk = [&](uint32_t kc, float4 (&st)[4]) {
+            if (kc + 1 < nkc) fetch_b(kc + 1, bhn, bln);   // ahead of the barriers: its registers were freed by the last copy
             if (kc > 0) __syncthreads();                   // the previous slice has been consumed (the first follows the tile's barrier)
 #pragma unroll
             for (int v = 0; v < 4; v += 2) {
-                const float x[8] = {stage[v].x - mid[v].x, stage[v].y - mid[v].y, stage[v].z - mid[v].z, stage[v].w - mid[v].w,
-                                    stage[v + 1].x - mid[v + 1].x, stage[v + 1].y - mid[v + 1].y, stage[v + 1].z - mid[v + 1].z, stage[v + 1].w - mid[v + 1].w};
+                const float4 m0 = *reinterpret_cast<const float4*>(mid_l + kc * KC2 + lhalf * 16 + v * 4);
+                const float4 m1 = *reinterpret_cast<const float4*>(mid_l + kc * KC2 + lhalf * 16 + v * 4 + 4);
+                const float x[8] = {st[v].x - m0.x, st[v].y - m0.y, st[v].z - m0.z, st[v].w - m0.w,
+                                    st[v + 1].x - m1.x, st[v + 1].y - m1.y, st[v + 1].z - m1.z, st[v + 1].w - m1.w};
                 bf16x8 hi, lo;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { __bf16 a, b; bf16_split(x[e], a, b); hi[e] = a; lo[e] = b; }
-                const int at = ab + lrow * LDK2 + lhalf * 16 + v * 4;
+                const int at = lrow * LDK2 + lhalf * 16 + v * 4;
                 *reinterpret_cast<bf16x8*>(Ah + at) = hi;
                 *reinterpret_cast<bf16x8*>(Al + at) = lo;
             }
             __syncthreads();
-            if (kc + 1 < nkc) { fetch_a(kc + 1); fetch_b(kc + 1, bhn, bln); }     // in flight during the contraction
+            if (kc + 2 < nkc) fetch_a(kc + 2, st);         // into the registers the split has just emptied
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const __bf16* arh = Ah + ab + (t * 32 + j) * LDK2 + 8 * h;
-                const __bf16* arl = Al + ab + (t * 32 + j) * LDK2 + 8 * h;
+                const __bf16* arh = Ah + (t * 32 + j) * LDK2 + 8 * h;
+                const __bf16* arl = Al + (t * 32 + j) * LDK2 + 8 * h;
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const bf16x8 ah = *reinterpret_cast<const bf16x8*>(arh + 16 * s);
@@ -656,6 +658,14 @@ __global__ void __launch_bounds__(256) knn_bf16_long_kernel(GraphView gv, const 
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) { bhq[s] = bhn[s]; blq[s] = bln[s]; }
+        };
+        __syncthreads();                                   // the previous tile's scale / bias and A slices are consumed
+        if (tid < LT) { const uint32_t rr = tb + tid; sc_t[tid] = rr < r_end ? scale[rr] : 0.f; bi_t[tid] = rr < r_end ? bias[rr] : INF_F; }
+        fetch_a(0, st0); fetch_b(0, bhq, blq);
+        if (nkc > 1) fetch_a(1, st1);
+        for (uint32_t kc = 0; kc < nkc; kc += 2) {         // nkc is even (the queries' planes are padded to 64 dimensions)
+            chunk(kc, st0);
+            chunk(kc + 1, st1);
         }
         // epilogue, one 32-row sub-tile at a time: acc[t][v] = q_j . x_i with i = t*32 + (v/4)*8 + h*4 + v%4
 #pragma unroll
@@ -787,7 +797,7 @@ uint32_t launch_mfma(const GraphView& g, const float* queries, uint32_t nq, cons
     return n_chunks;
 }
 // padded row length of the bf16 planes of the queries
-inline uint32_t knn_bf16_k(uint32_t stride) { return stride <= 64 ? 64u : stride <= 128 ? 128u : stride <= 256 ? 256u : (stride + 31u) / 32u * 32u; }
+inline uint32_t knn_bf16_k(uint32_t stride) { return stride <= 64 ? 64u : stride <= 128 ? 128u : stride <= 256 ? 256u : (stride + 63u) / 64u * 64u; }
 template <int KS, int KP, int WPB>
 uint32_t launch_bf16(const GraphView& g, const __bf16* qh, const __bf16* ql, uint32_t nq, const float* centre, const float* scale, const float* bias, uint32_t* slots, uint32_t max_chunks, hipStream_t st) {
     constexpr int K = 16 * KS, MQB = 32 * WPB;
@@ -805,7 +815,7 @@ uint32_t launch_bf16_any(const GraphView& g, const __bf16* qh, const __bf16* ql,
     if (g.stride <= 64) return launch_bf16<4, KP, 4>(g, qh, ql, nq, centre, scale, bias, slots, max_chunks, st);
     if (g.stride <= 128) return launch_bf16<8, KP, 4>(g, qh, ql, nq, centre, scale, bias, slots, max_chunks, st);
     if (g.stride <= 256) return launch_bf16<16, KP, 8>(g, qh, ql, nq, centre, scale, bias, slots, max_chunks, st);
-    const size_t lds = (size_t)2 * LT * LDK2 * 2 + 2 * LT * 4 + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8;
+    const size_t lds = (size_t)2 * LT * LDK2 * 2 + 2 * LT * 4 + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8 + (size_t)knn_bf16_k(g.stride) * 4;
     const uint32_t n_chunks = pick_chunks(g.n, nq, MQ, resident_blocks(knn_bf16_long_kernel<KP>, lds), max_chunks);
     hipLaunchKernelGGL((knn_bf16_long_kernel<KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, qh, ql, knn_bf16_k(g.stride), nq, centre, scale, bias, slots, n_chunks);
     return n_chunks;
