@@ -87,6 +87,9 @@ __device__ __forceinline__ void knn_admit_tile(const GraphView& gv, const float 
 #pragma unroll
     for (int v = 1; v < 16; ++v) mn = __builtin_fminf(mn, key[v]);
     if (!__ballot(qvalid && mn <= thr)) return;
+    // The rest holds up the block's next barrier, and while the SIMD's other wave streams MFMAs this wave's vector
+    // instructions would only issue in its gaps: ask for the issue slots until the keys are in.
+    __builtin_amdgcn_s_setprio(3);
     uint32_t m = 0, eq = 0;
 #pragma unroll
     for (int v = 0; v < 16; ++v) { m |= (key[v] < thr ? 1u : 0u) << v; eq |= (key[v] == thr ? 1u : 0u) << v; }
@@ -127,6 +130,7 @@ __device__ __forceinline__ void knn_admit_tile(const GraphView& gv, const float 
                 if (((m >> v) & 1u) && !(key[v] < thr || (key[v] == thr && knn_tie_admits(gv, row0 + (v / 4) * 8 + h * 4 + (v % 4), thr_row)))) m &= ~(1u << v);
         }
     }
+    __builtin_amdgcn_s_setprio(0);
 }
 
 // scale / bias turn a dot product into the ranking key: key = dot * scale[row] + bias[row].
@@ -812,9 +816,10 @@ uint32_t launch_bf16(const GraphView& g, const __bf16* qh, const __bf16* ql, uin
 }
 template <int KP>
 uint32_t launch_bf16_any(const GraphView& g, const __bf16* qh, const __bf16* ql, uint32_t nq, const float* centre, const float* scale, const float* bias, uint32_t* slots, uint32_t max_chunks, hipStream_t st) {
-    if (g.stride <= 64) return launch_bf16<4, KP, 4>(g, qh, ql, nq, centre, scale, bias, slots, max_chunks, st);
-    if (g.stride <= 128) return launch_bf16<8, KP, 4>(g, qh, ql, nq, centre, scale, bias, slots, max_chunks, st);
-    if (g.stride <= 256) return launch_bf16<16, KP, 8>(g, qh, ql, nq, centre, scale, bias, slots, max_chunks, st);
+    const bool force_long = std::getenv("VDB_KNN_LONG") != nullptr;   // diagnostic: the chunked kernel on short rows
+    if (!force_long && g.stride <= 64) return launch_bf16<4, KP, 4>(g, qh, ql, nq, centre, scale, bias, slots, max_chunks, st);
+    if (!force_long && g.stride <= 128) return launch_bf16<8, KP, 4>(g, qh, ql, nq, centre, scale, bias, slots, max_chunks, st);
+    if (!force_long && g.stride <= 256) return launch_bf16<16, KP, 8>(g, qh, ql, nq, centre, scale, bias, slots, max_chunks, st);
     const size_t lds = (size_t)2 * LT * LDK2 * 2 + 2 * LT * 4 + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8 + (size_t)knn_bf16_k(g.stride) * 4;
     const uint32_t n_chunks = pick_chunks(g.n, nq, MQ, resident_blocks(knn_bf16_long_kernel<KP>, lds), max_chunks);
     hipLaunchKernelGGL((knn_bf16_long_kernel<KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, qh, ql, knn_bf16_k(g.stride), nq, centre, scale, bias, slots, n_chunks);
