@@ -107,13 +107,20 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch                                   # before libvdbmi: one HIP runtime per process
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal of the multi-rank step on a box with ONE GPU: VDB_BENCH_REHEARSAL=gloo puts every rank on device 0 and
+    # exchanges through gloo (host-staged) instead of RCCL, which refuses two ranks on one device.  Never set by the driver.
+    rehearsal = os.environ.get("VDB_BENCH_REHEARSAL", "")
+    gpu_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
     # VDB_BENCH_EXCHANGE=1 under torchrun with one rank rehearses the multi-GPU step (all-gather + merge) on one GPU
     exchange = world > 1 or (os.environ.get("VDB_BENCH_EXCHANGE") == "1" and "RANK" in os.environ)
     if exchange:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group(rehearsal)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     import vectordb_amd
     vdb = vectordb_amd.api()
 
@@ -131,7 +138,7 @@ def main():
 
     # ---- build the shard's graph on the GPU (hnsw.rs:119-208 linking rules, batched rounds) ----
     t0 = time.time()
-    index = vdb.HNSWIndex(vdb.DistanceMetric(METRIC), M, EF_BUILD, 16, D, seed=SEED + rank, device=local_rank, arith=vdb.Arith.Fast)
+    index = vdb.HNSWIndex(vdb.DistanceMetric(METRIC), M, EF_BUILD, 16, D, seed=SEED + rank, device=gpu_index, arith=vdb.Arith.Fast)
     step = 250_000
     for s in range(0, N, step):
         index.insert_batch(ids[s:s + step], base[s:s + step])
@@ -254,7 +261,7 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     if exchange:
-        tt = torch.tensor([wall], dtype=torch.float64, device=dev)
+        tt = torch.tensor([wall], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
     ms_per_step = wall * 1e3 / args.steps

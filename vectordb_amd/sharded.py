@@ -92,10 +92,19 @@ class ShardedIndex:
             return d_out, d_cnt
         if not gathered:
             import torch.distributed as dist
-            g_out = torch.empty(self.world * d_out.numel(), dtype=torch.uint8, device=d_out.device)
-            g_cnt = torch.empty(self.world * nq, dtype=torch.int32, device=d_out.device)
-            dist.all_gather_into_tensor(g_out, d_out, group=self.group)
-            dist.all_gather_into_tensor(g_cnt, d_cnt, group=self.group)
+            if dist.get_backend(self.group) == "nccl":
+                g_out = torch.empty(self.world * d_out.numel(), dtype=torch.uint8, device=d_out.device)
+                g_cnt = torch.empty(self.world * nq, dtype=torch.int32, device=d_out.device)
+                dist.all_gather_into_tensor(g_out, d_out, group=self.group)
+                dist.all_gather_into_tensor(g_cnt, d_cnt, group=self.group)
+            else:
+                # a host-side backend (gloo rehearsals on a box with one GPU): the lists are staged through host memory
+                h_out, h_cnt = d_out.cpu(), d_cnt.cpu()
+                gh_out = torch.empty(self.world * h_out.numel(), dtype=torch.uint8)
+                gh_cnt = torch.empty(self.world * nq, dtype=torch.int32)
+                dist.all_gather_into_tensor(gh_out, h_out, group=self.group)
+                dist.all_gather_into_tensor(gh_cnt, h_cnt, group=self.group)
+                g_out, g_cnt = gh_out.to(d_out.device), gh_cnt.to(d_out.device)
             d_out, d_cnt = g_out, g_cnt
         m_out = torch.empty(nq * k * 16, dtype=torch.uint8, device=d_out.device)
         m_cnt = torch.empty(nq, dtype=torch.int32, device=d_out.device)
