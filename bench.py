@@ -74,7 +74,7 @@ def recall_at_k(ann, ann_n, exact, k):
 CONFIGS = {
     "c2": dict(n=1_000_000, dim=128, queries=10_000, metric=2, centres=4096, seed=0xC2, efs=[16, 32, 64, 96, 128, 144, 160, 176, 192, 224, 256],
                metric_name="queries/sec at recall@10>=0.95 (1M x 128 L2)", shape="SIFT1M-shape"),
-    "c3": dict(n=1_000_000, dim=960, queries=1_000, metric=0, centres=1024, seed=0xC3, efs=[64, 128, 192, 256, 384, 512],
+    "c3": dict(n=1_000_000, dim=960, queries=1_000, metric=0, centres=1024, seed=0xC3, efs=[64, 128, 192, 256, 384, 512], streams=6,
                metric_name="queries/sec at recall@10>=0.95 (1M x 960 cosine)", shape="GIST-shape"),
     "c5": dict(n=12_500_000, dim=96, queries=10_000, metric=2, centres=4096, seed=0xC5, efs=[32, 64, 128, 256],
                metric_name="queries/sec (100M x 96 L2 over 8 shards), recall@10 reported", shape="Deep100M-shape"),
@@ -96,9 +96,10 @@ def main():
     ap.add_argument("--target-recall", type=float, default=0.95)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=0, help="queries of the CPU baseline sample (0 = all for c2, 1000 otherwise)")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams the timed steps rotate over (consecutive batches overlap, which hides the tail of "
-                         "long-running queries at the end of each launch); 1 = strictly back to back")
+                         "long-running queries at the end of each launch); 1 = strictly back to back; 0 = the configuration's "
+                         "(2; 6 for c3, whose 1000-query launches leave most of the machine idle while their longest walks end)")
     args = ap.parse_args()
     if args.config == "c4":
         return bench_c4(args)
@@ -213,7 +214,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    n_streams = max(1, args.streams)
+    n_streams = max(1, args.streams or cfg.get("streams", 2))
     lanes = [(stream, d_out, d_n, d_stats)]
     for _ in range(n_streams - 1):
         lanes.append((torch.cuda.Stream(device=dev), torch.zeros_like(d_out), torch.zeros_like(d_n), torch.zeros_like(d_stats)))

@@ -5,12 +5,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import clustered
 import vectordb_amd
 vdb = vectordb_amd.api()
-n, d, nq, k = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000, 128, 10000, 10
+# usage: timing_probe.py [rows] [ef] [dim] [queries] [centres] [metric]   (defaults: the 1M x 128 L2 benchmark; C3: 1000000 384 960 1000 1024 0)
+n, k = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000, 10
 ef = int(sys.argv[2]) if len(sys.argv) > 2 else 192
-centres = np.random.default_rng(0xC2).uniform(0, 128, size=(4096, d)).astype(np.float32)
+d = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+nq = int(sys.argv[4]) if len(sys.argv) > 4 else 10000
+nc = int(sys.argv[5]) if len(sys.argv) > 5 else 4096
+metric = int(sys.argv[6]) if len(sys.argv) > 6 else 2
+centres = np.random.default_rng(0xC2).uniform(0, 128, size=(nc, d)).astype(np.float32)
 base = clustered(n, d, 0xC3, centres); q = clustered(nq, d, 0xC2 + 1000, centres)
-h = vdb.HNSWIndex(vdb.DistanceMetric.Euclidean, 16, 64, 16, d, seed=0xC2)
-h.insert_batch(np.arange(n, dtype=np.uint64), base)
+h = vdb.HNSWIndex(vdb.DistanceMetric(metric), 16, 64, 16, d, seed=0xC2)
+for s0 in range(0, n, 250_000):
+    h.insert_batch(np.arange(s0, min(n, s0 + 250_000), dtype=np.uint64), base[s0:s0 + 250_000])
 for _ in range(2):
     t0 = time.perf_counter()
     out, cnt, st = h.search_batch(q, k, ef_search=ef, with_stats=True)
