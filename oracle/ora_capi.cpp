@@ -285,6 +285,7 @@ int ora_index_export_sizes(const HNSWIndex* x, size_t* n, size_t* n_layers, size
 }
 int ora_index_export_points(const HNSWIndex* x, uint64_t* ids, uint32_t* levels, float* vectors, uint8_t* deleted) {
     size_t n = x->ids.size();
+    if (n == 0) return 0;                                  // empty vectors may hand out a null data()
     if (ids) std::memcpy(ids, x->ids.data(), n * 8);
     if (levels) for (size_t i = 0; i < n; ++i) levels[i] = (uint32_t)x->levels[i];
     if (vectors) std::memcpy(vectors, x->vecs.data(), n * x->dim * 4);

@@ -24,7 +24,8 @@ def build(force=False):
 def load():
     sys.path.insert(0, os.path.dirname(_HERE))
     from vectordb_amd import capi
-    lib = ctypes.CDLL(build())
+    # VDB_ORACLE_LIBRARY: another build of the same sources (tools/sanitize_host.sh: AddressSanitizer + UBSan)
+    lib = ctypes.CDLL(os.environ.get("VDB_ORACLE_LIBRARY") or build())
     api = capi.bind(lib, prefix="ora_", required=set())
     api.set_threads = api.fn.set_threads
     return api
