@@ -65,10 +65,11 @@ __global__ void __launch_bounds__(256) scan_strict_kernel(const float* __restric
     }
 }
 
-// Shape of the FAST scan, from measurements on 1M x 768 / 960 rows against 8 queries: two rows per lane group and
-// step (one row doubles the LDS reads and is 8 % slower), one step of rows in flight (two or three are no faster:
-// with eight queries the kernel is bound by LDS reads and issue, not by bytes in flight), all queries of the block in
-// one pass over the rows' registers.
+// Shape of the FAST scan, from measurements on 1M x 32 .. 1536 rows against 8 queries: four rows per lane group and
+// step for most row lengths (the queries are read from LDS once per step: one row per step is 8 % slower than two,
+// two 4-6 % slower than four, eight slower again), the step's rows fetched and scored in one buffer (with four rows
+// per step a second buffer in flight adds nothing: the other wavefronts of the CU cover the fetch), all queries of
+// the block in one pass over the rows' registers.
 constexpr int SCAN_QH = 8, SCAN_QB = 1, SCAN_NB = 2;
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 
@@ -300,11 +301,13 @@ void launch_score_scan(const float* queries, uint32_t nq, const float* base, uin
         const uint32_t chunks = qpad / 4;
         const uint32_t blocks = 256 * 8;
         const uint32_t qt = nq >= 5 ? 8u : nq >= 3 ? 4u : nq;          // queries a block scores (the last block may hold fewer)
-#define VDB_SCAN_Q(G, CH, R, QT) lds = (size_t)QT * G * CH * 16; hipLaunchKernelGGL((scan_fast_kernel<G, CH, R, QT, SCAN_NB>), dim3(blocks, qblocks), dim3(256), lds, st, queries, nq, base, n, dim, stride, metric, out)
-#define VDB_SCAN(G, CH, R) do { if (qt == 8) { VDB_SCAN_Q(G, CH, R, 8); } else if (qt == 4) { VDB_SCAN_Q(G, CH, R, 4); } else if (qt == 2) { VDB_SCAN_Q(G, CH, R, 2); } else { VDB_SCAN_Q(G, CH, R, 1); } } while (0)
-        if (chunks <= 8) VDB_SCAN(8, 1, 4); else if (chunks <= 16) VDB_SCAN(8, 2, 2); else if (chunks <= 24) VDB_SCAN(8, 3, 2);
-        else if (chunks <= 32) VDB_SCAN(8, 4, 2); else if (chunks <= 64) VDB_SCAN(16, 4, 2); else if (chunks <= 128) VDB_SCAN(32, 4, 2);
-        else if (chunks <= 192) VDB_SCAN(64, 3, 2); else if (chunks <= 256) VDB_SCAN(64, 4, 2); else VDB_SCAN(64, 8, 1);
+#define VDB_SCAN_Q(G, CH, R, NB, QT) lds = (size_t)QT * G * CH * 16; hipLaunchKernelGGL((scan_fast_kernel<G, CH, R, QT, NB>), dim3(blocks, qblocks), dim3(256), lds, st, queries, nq, base, n, dim, stride, metric, out)
+#define VDB_SCAN(G, CH, R, NB) do { if (qt == 8) { VDB_SCAN_Q(G, CH, R, NB, 8); } else if (qt == 4) { VDB_SCAN_Q(G, CH, R, NB, 4); } else if (qt == 2) { VDB_SCAN_Q(G, CH, R, NB, 2); } else { VDB_SCAN_Q(G, CH, R, NB, 1); } } while (0)
+        // rows of up to 32 and of 97..128 floats: two row buffers in turn; the other shapes: twice the rows per step in one
+        // buffer (half the LDS reads of the queries per row; measured 2-9 % faster there, slower on the two shapes above)
+        if (chunks <= 8) VDB_SCAN(8, 1, 4, SCAN_NB); else if (chunks <= 16) VDB_SCAN(8, 2, 4, 1); else if (chunks <= 24) VDB_SCAN(8, 3, 4, 1);
+        else if (chunks <= 32) VDB_SCAN(8, 4, 2, SCAN_NB); else if (chunks <= 64) VDB_SCAN(16, 4, 4, 1); else if (chunks <= 128) VDB_SCAN(32, 4, 4, 1);
+        else if (chunks <= 192) VDB_SCAN(64, 3, 4, 1); else if (chunks <= 256) VDB_SCAN(64, 4, 4, 1); else VDB_SCAN(64, 8, 2, 1);
 #undef VDB_SCAN_Q
 #undef VDB_SCAN
     }
