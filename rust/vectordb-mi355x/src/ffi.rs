@@ -1,4 +1,5 @@
-//! Raw bindings of include/vdbmi.h (the subset the wrappers call; `bindgen include/vdbmi.h` produces all of it).
+//! Raw bindings of include/vdbmi.h: every entry point of the header (the second `extern` block was produced from the
+//! header by tools/gen_rust_ffi.py; enums travel as `c_int`).
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_double, c_int, c_void};
 
@@ -7,10 +8,19 @@ use std::os::raw::{c_char, c_double, c_int, c_void};
 #[repr(C)] pub struct vdb_value { _p: [u8; 0] }
 #[repr(C)] pub struct vdb_payload { _p: [u8; 0] }
 #[repr(C)] pub struct vdb_filter { _p: [u8; 0] }
+#[repr(C)] pub struct vdb_payload_index { _p: [u8; 0] }
 
 /// ScoredPoint, src/vector/hnsw.rs:11-16
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct vdb_scored_point { pub id: u64, pub raw_score: f32, pub sort_key: f32 }
+
+/// per-query work counters (vdbmi.h: vdb_query_stats)
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct vdb_query_stats { pub rows_scored: u32, pub expanded: u32, pub adj_entries: u32, pub flags: u32 }
+
+/// one layer of a graph handed over in CSR form (vdbmi.h: vdb_layer_csr)
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct vdb_layer_csr { pub n_lists: usize, pub owners: *const u32, pub offsets: *const u64, pub neighbors: *const u32, pub n_edges: usize }
 
 #[repr(C)] #[derive(Clone, Copy)]
 pub struct vdb_options { pub seed: u64, pub device: i32, pub arith: i32, pub filter_mode: i32, pub beam_width: i32 }
@@ -86,4 +96,54 @@ extern "C" {
                                     out: *mut vdb_scored_point, out_n: *mut u32) -> c_int;
     pub fn vdb_segment_save(s: *const vdb_segment, path: *const c_char) -> c_int;
     pub fn vdb_segment_load(s: *mut vdb_segment, path: *const c_char) -> c_int;
+}
+
+// the rest of the header, declared mechanically (tools/gen_rust_ffi.py)
+extern "C" {
+    pub fn vdb_device_count() -> c_int;
+    pub fn vdb_score_scan(queries: *const f32, nq: usize, base: *const f32, n: usize, dim: usize, metric: c_int, arith: c_int, device: c_int, out: *mut f32) -> c_int;
+    pub fn vdb_score_scan_dev(d_queries: *const f32, nq: usize, d_base: *const f32, n: usize, dim: usize, stride: usize, metric: c_int, arith: c_int, d_out: *mut f32, stream: *mut c_void) -> c_int;
+    pub fn vdb_value_type(v: *const vdb_value) -> c_int;
+    pub fn vdb_value_equals(a: *const vdb_value, b: *const vdb_value) -> c_int;
+    pub fn vdb_value_compare_scalar(a: *const vdb_value, op: c_int, b: *const vdb_value, is_some: *mut c_int, out: *mut c_int) -> c_int;
+    pub fn vdb_value_evaluate_list_query(self_: *const vdb_value, kind: c_int, op: c_int, n: usize, v: *const vdb_value, is_some: *mut c_int, out: *mut c_int) -> c_int;
+    pub fn vdb_payload_get(p: *const vdb_payload, key: *const c_char) -> *const vdb_value;
+    pub fn vdb_payload_compare_field(p: *const vdb_payload, field: *const c_char, op: c_int, other: *const vdb_value, out: *mut c_int) -> c_int;
+    pub fn vdb_payload_evaluate_list_field(p: *const vdb_payload, field: *const c_char, kind: c_int, op: c_int, n: usize, v: *const vdb_value, out: *mut c_int) -> c_int;
+    pub fn vdb_filter_evaluate(f: *const vdb_filter, p: *const vdb_payload, out: *mut c_int) -> c_int;
+    pub fn vdb_payload_index_new() -> *mut vdb_payload_index;
+    pub fn vdb_payload_index_free(x: *mut vdb_payload_index);
+    pub fn vdb_payload_index_insert(x: *mut vdb_payload_index, id: u64, p: *const vdb_payload) -> c_int;
+    pub fn vdb_payload_index_remove(x: *mut vdb_payload_index, id: u64, p: *const vdb_payload) -> c_int;
+    pub fn vdb_payload_index_query_exact(x: *const vdb_payload_index, key: *const c_char, v: *const vdb_value, out_ids: *mut u64, cap: usize, out_n: *mut usize, is_some: *mut c_int) -> c_int;
+    pub fn vdb_payload_index_all_for_key(x: *const vdb_payload_index, key: *const c_char, out_ids: *mut u64, cap: usize, out_n: *mut usize, is_some: *mut c_int) -> c_int;
+    pub fn vdb_index_search_batch_dev(x: *const vdb_index, d_queries: *const f32, nq: usize, top_k: usize, ef_search: usize, d_out: *mut vdb_scored_point, d_out_n: *mut u32, d_stats: *mut vdb_query_stats, stream: *mut c_void) -> c_int;
+    pub fn vdb_index_exact_knn_batch(x: *const vdb_index, queries: *const f32, nq: usize, len: usize, top_k: usize, out: *mut vdb_scored_point, out_n: *mut u32) -> c_int;
+    pub fn vdb_index_exact_knn_batch_dev(x: *const vdb_index, d_queries: *const f32, nq: usize, top_k: usize, d_out: *mut vdb_scored_point, d_out_n: *mut u32, stream: *mut c_void) -> c_int;
+    pub fn vdb_index_exact_knn_batch_dev_noalloc(x: *const vdb_index, d_queries: *const f32, nq: usize, top_k: usize, d_out: *mut vdb_scored_point, d_out_n: *mut u32, stream: *mut c_void) -> c_int;
+    pub fn vdb_index_metric(x: *const vdb_index) -> c_int;
+    pub fn vdb_index_m(x: *const vdb_index) -> usize;
+    pub fn vdb_index_ef(x: *const vdb_index) -> usize;
+    pub fn vdb_index_max_level_cap(x: *const vdb_index) -> usize;
+    pub fn vdb_index_dim(x: *const vdb_index) -> usize;
+    pub fn vdb_index_normalize_score(x: *const vdb_index, raw: f32) -> f32;
+    pub fn vdb_index_import_graph(x: *mut vdb_index, n: usize, ids: *const u64, levels: *const u32, vectors: *const f32, deleted: *const u8, n_layers: usize, layers: *const vdb_layer_csr, has_entry: c_int, entry_id: u64, current_max_level: usize) -> c_int;
+    pub fn vdb_index_export_sizes(x: *const vdb_index, n: *mut usize, n_layers: *mut usize, n_lists: *mut usize, n_edges: *mut usize, cap_layers: usize) -> c_int;
+    pub fn vdb_index_export_points(x: *const vdb_index, ids: *mut u64, levels: *mut u32, vectors: *mut f32, deleted: *mut u8) -> c_int;
+    pub fn vdb_index_export_layer(x: *const vdb_index, level: usize, owners: *mut u32, offsets: *mut u64, neighbors: *mut u32) -> c_int;
+    pub fn vdb_index_save(x: *const vdb_index, path: *const c_char) -> c_int;
+    pub fn vdb_index_load(x: *mut vdb_index, path: *const c_char) -> c_int;
+    pub fn vdb_index_device_info(x: *const vdb_index, n_slots: *mut usize, row_stride_floats: *mut usize, l0_edges: *mut usize, upper_edges: *mut usize, bytes_total: *mut usize) -> c_int;
+    pub fn vdb_index_sync_device(x: *mut vdb_index) -> c_int;
+    pub fn vdb_segment_insert_batch(s: *mut vdb_segment, v: *const f32, n: usize, len: usize, payloads: *const *const vdb_payload, out_ids: *mut u64) -> c_int;
+    pub fn vdb_segment_insert_batch_columns(s: *mut vdb_segment, v: *const f32, n: usize, len: usize, n_keys: usize, keys: *const *const c_char, kinds: *const i32, cols: *const *const c_void, out_ids: *mut u64) -> c_int;
+    pub fn vdb_segment_get_vector(s: *const vdb_segment, id: u64, out: *mut f32, cap: usize) -> c_int;
+    pub fn vdb_segment_get_payload(s: *const vdb_segment, id: u64) -> *const vdb_payload;
+    pub fn vdb_segment_hnsw(s: *const vdb_segment) -> *const vdb_index;
+    pub fn vdb_segment_payload_index(s: *const vdb_segment) -> *const vdb_payload_index;
+    pub fn vdb_segment_payload_count(s: *const vdb_segment) -> usize;
+    pub fn vdb_segment_search_batch_dev(s: *const vdb_segment, d_queries: *const f32, nq: usize, top_k: usize, ef_search: usize, f: *const vdb_filter, d_out: *mut vdb_scored_point, d_out_n: *mut u32, d_stats: *mut vdb_query_stats, stream: *mut c_void) -> c_int;
+    pub fn vdb_segment_compile_filter(s: *const vdb_segment, f: *const vdb_filter, n_pass: *mut usize, n_err: *mut usize) -> c_int;
+    pub fn vdb_segment_filter_bitmaps(s: *const vdb_segment, f: *const vdb_filter, pass: *mut u32, err: *mut u32, cap_words: usize) -> c_int;
+    pub fn vdb_topk_merge_dev(d_lists: *const vdb_scored_point, d_counts: *const u32, n_shards: usize, nq: usize, k: usize, d_out: *mut vdb_scored_point, d_out_n: *mut u32, stream: *mut c_void) -> c_int;
 }
