@@ -72,6 +72,8 @@ def recall_at_k(ann, ann_n, exact, k):
 
 # name -> rows per rank, dimension, queries, metric (DistanceMetric value), Gaussian centres, generator seed, ef candidates
 CONFIGS = {
+    "c1": dict(n=10_000, dim=128, queries=1_000, metric=0, centres=0, seed=0xC1, efs=[64], streams=2,
+               metric_name="queries/sec, 10k x 128 cosine, HNSW M=16 ef=64 (the reference's own test shape), recall@10 reported", shape="tests/hnsw.rs-shape"),
     "c2": dict(n=1_000_000, dim=128, queries=10_000, metric=2, centres=4096, seed=0xC2, efs=[16, 32, 64, 96, 128, 144, 160, 176, 192, 224, 256],
                metric_name="queries/sec at recall@10>=0.95 (1M x 128 L2)", shape="SIFT1M-shape"),
     "c3": dict(n=1_000_000, dim=960, queries=1_000, metric=0, centres=1024, seed=0xC3, efs=[64, 128, 192, 256, 384, 512], streams=6,
@@ -86,7 +88,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
     ap.add_argument("--c5-total", type=int, default=0, help="c5: total rows over all ranks (strong scaling); 0 = 12.5M per rank")
     ap.add_argument("--n", type=int, default=0, help="rows per rank (0 = the configuration's)")
     ap.add_argument("--dim", type=int, default=0)
@@ -131,9 +133,13 @@ def main():
     METRIC, SEED = cfg["metric"], cfg["seed"]
     M, EF_BUILD = 16, 64
     t0 = time.time()
-    centres = np.random.default_rng(SEED).uniform(0, 128, size=(cfg["centres"], D)).astype(np.float32)
-    base = clustered(N, D, SEED + 1 + rank, centres)
-    queries = clustered(Q, D, SEED + 1000, centres)
+    if cfg["centres"]:
+        centres = np.random.default_rng(SEED).uniform(0, 128, size=(cfg["centres"], D)).astype(np.float32)
+        base = clustered(N, D, SEED + 1 + rank, centres)
+        queries = clustered(Q, D, SEED + 1000, centres)
+    else:                                                        # c1: uniform(-1, 1) per coordinate, like generate_points of tests/hnsw.rs:12-26
+        base = np.random.default_rng(SEED + rank).uniform(-1, 1, size=(N, D)).astype(np.float32)
+        queries = np.random.default_rng(SEED + 1000).uniform(-1, 1, size=(Q, D)).astype(np.float32)
     ids = np.arange(N, dtype=np.uint64) + np.uint64(rank) * np.uint64(N)
     log(f"data: {N}x{D} base (shard {rank}/{world}), {Q} queries in {time.time()-t0:.1f}s")
 
@@ -273,7 +279,7 @@ def main():
         "metric": cfg["metric_name"], "value": value, "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{cfg['shape']} synthetic: {N} x {D} fp32 {('cosine', 'dot', 'L2')[METRIC]} per GPU (clustered, {cfg['centres']} Gaussian centres), "
+        "config": {"workload": f"{cfg['shape']} synthetic: {N} x {D} fp32 {('cosine', 'dot', 'L2')[METRIC]} per GPU ({'clustered, ' + str(cfg['centres']) + ' Gaussian centres' if cfg['centres'] else 'uniform(-1, 1) coordinates'}), "
                                f"{Q}-query batch, HNSW M={M} ef_construction={EF_BUILD}, top-{K}",
                    "rccl_ranks": world if exchange else 0, "total_rows": N * world,
                    "ef_search": ef, "recall_at_10": sweep[ef]["recall"], "ef_sweep": sweep, "shards": world,
