@@ -216,7 +216,8 @@ vdb_status vdb_index_search_batch_dev(const vdb_index* x, const float* d_queries
                                       size_t ef_search, vdb_scored_point* d_out, uint32_t* d_out_n,
                                       vdb_query_stats* d_stats, void* stream);
 /* Exact k-NN over all live points (extension, no reference function; defined by score() +
- * normalize_score() + (sort_key asc, id asc)): MFMA contraction + fused top-k + strict re-rank. */
+ * normalize_score() + (sort_key asc, id asc)): MFMA contraction + fused top-k + strict re-rank.
+ * 1 <= top_k <= 256 (0 returns nothing); a larger top_k is VDB_ERR_ARGUMENT.  Fewer live points than top_k: all of them. */
 vdb_status vdb_index_exact_knn_batch(const vdb_index* x, const float* queries, size_t nq, size_t len, size_t top_k,
                                      vdb_scored_point* out, uint32_t* out_n);
 vdb_status vdb_index_exact_knn_batch_dev(const vdb_index* x, const float* d_queries, size_t nq, size_t top_k,
