@@ -96,3 +96,39 @@ def test_wrong_query_length_and_the_largest_dimension(vdb, ora):
     ex, exn = hp.exact_knn_batch(q, 5)
     rex, rexn = ho.exact_knn_batch(q, 5)
     assert np.array_equal(ex["id"], rex["id"])
+
+
+def test_segment_batches_with_filters_that_pass_nothing_everything_and_after_deleting_all(vdb):
+    """Segment::search_with_filter in batches (segment.rs:121-147; Masked mode): a filter no payload satisfies returns
+    nothing, one that every payload satisfies returns k passing rows in ascending order — also for k beyond the 64
+    rows the register-resident passing list holds —, and a segment whose points are all deleted is SearchError
+    (segment.rs:104-107, 126-130)."""
+    n, d = 1500, 24
+    rng = np.random.default_rng(91)
+    x = rng.normal(size=(n, d)).astype(np.float32)
+    seg = vdb.Segment(vdb.HNSWIndex(vdb.DistanceMetric.Euclidean, 8, 64, 16, d, seed=3, arith=vdb.Arith.Fast, filter_mode=vdb.FilterMode.Masked))
+    pays = []
+    for i in range(n):
+        p = vdb.Payload(); p.set("all", vdb.PayloadValue.Int(1)); p.set("odd", vdb.PayloadValue.Int(i % 2)); pays.append(p)
+    ids = seg.insert_batch(x, pays)
+    q = rng.normal(size=(33, d)).astype(np.float32)
+    out, cnt = seg.search_batch(q, 10, filter=vdb.Filter.Match("all", vdb.PayloadValue.Int(7)))
+    assert (cnt == 0).all()
+    for k in (10, 100):
+        out, cnt = seg.search_batch(q, k, ef_search=128, filter=vdb.Filter.Match("all", vdb.PayloadValue.Int(1)))
+        assert (cnt == k).all() and (np.diff(out["sort_key"], axis=1) >= 0).all()
+        out, cnt = seg.search_batch(q, k, ef_search=128, filter=vdb.Filter.Match("odd", vdb.PayloadValue.Int(1)))
+        assert (cnt == k).all() and (np.diff(out["sort_key"], axis=1) >= 0).all()
+        odd = {int(ids[i]) for i in range(n) if i % 2 == 1}
+        assert all(int(v) in odd for v in out["id"].reshape(-1))
+        # distances are the rows' own (float64 recomputation)
+        slot = {int(ids[i]): i for i in range(n)}
+        for qi in (0, 17):
+            rows = x[[slot[int(v)] for v in out["id"][qi]]]
+            ref = np.sqrt(((rows.astype(np.float64) - q[qi].astype(np.float64)) ** 2).sum(axis=1))
+            assert np.allclose(out["sort_key"][qi], ref, rtol=1e-5)
+    for i in ids:
+        seg.delete(int(i))
+    with pytest.raises(vdb.DBError) as e:
+        seg.search_batch(q, 10)
+    assert "No active points" in str(e.value)
