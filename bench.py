@@ -278,7 +278,7 @@ def main():
     result = {
         "metric": cfg["metric_name"], "value": value, "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if (args.config == "c5" and args.c5_total) else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{cfg['shape']} synthetic: {N} x {D} fp32 {('cosine', 'dot', 'L2')[METRIC]} per GPU ({'clustered, ' + str(cfg['centres']) + ' Gaussian centres' if cfg['centres'] else 'uniform(-1, 1) coordinates'}), "
                                f"{Q}-query batch, HNSW M={M} ef_construction={EF_BUILD}, top-{K}",
                    "rccl_ranks": world if exchange else 0, "total_rows": N * world,
