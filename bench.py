@@ -74,6 +74,8 @@ def recall_at_k(ann, ann_n, exact, k):
 CONFIGS = {
     "c1": dict(n=10_000, dim=128, queries=1_000, metric=0, centres=0, seed=0xC1, efs=[64], streams=2,
                metric_name="queries/sec, 10k x 128 cosine, HNSW M=16 ef=64 (the reference's own test shape), recall@10 reported", shape="tests/hnsw.rs-shape"),
+    "c2u": dict(n=1_000_000, dim=128, queries=10_000, metric=2, centres=0, uniform=(0.0, 1.0), seed=0xC2, efs=[64, 128, 256, 512],
+                metric_name="queries/sec at recall@10>=0.95 (1M x 128 L2, uniform(0, 1) stress variant)", shape="uniform stress"),
     "c2": dict(n=1_000_000, dim=128, queries=10_000, metric=2, centres=4096, seed=0xC2, efs=[16, 32, 64, 96, 128, 144, 160, 176, 192, 224, 256],
                metric_name="queries/sec at recall@10>=0.95 (1M x 128 L2)", shape="SIFT1M-shape"),
     "c3": dict(n=1_000_000, dim=960, queries=1_000, metric=0, centres=1024, seed=0xC3, efs=[64, 128, 192, 256, 384, 512], streams=6,
@@ -88,7 +90,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c2u", "c3", "c4", "c5"])
     ap.add_argument("--c5-total", type=int, default=0, help="c5: total rows over all ranks (strong scaling); 0 = 12.5M per rank")
     ap.add_argument("--n", type=int, default=0, help="rows per rank (0 = the configuration's)")
     ap.add_argument("--dim", type=int, default=0)
@@ -138,8 +140,9 @@ def main():
         base = clustered(N, D, SEED + 1 + rank, centres)
         queries = clustered(Q, D, SEED + 1000, centres)
     else:                                                        # c1: uniform(-1, 1) per coordinate, like generate_points of tests/hnsw.rs:12-26
-        base = np.random.default_rng(SEED + rank).uniform(-1, 1, size=(N, D)).astype(np.float32)
-        queries = np.random.default_rng(SEED + 1000).uniform(-1, 1, size=(Q, D)).astype(np.float32)
+        lo, hi = cfg.get("uniform", (-1.0, 1.0))
+        base = np.random.default_rng(SEED + rank).uniform(lo, hi, size=(N, D)).astype(np.float32)
+        queries = np.random.default_rng(SEED + 1000).uniform(lo, hi, size=(Q, D)).astype(np.float32)
     ids = np.arange(N, dtype=np.uint64) + np.uint64(rank) * np.uint64(N)
     log(f"data: {N}x{D} base (shard {rank}/{world}), {Q} queries in {time.time()-t0:.1f}s")
 
@@ -279,7 +282,7 @@ def main():
         "metric": cfg["metric_name"], "value": value, "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong" if (args.config == "c5" and args.c5_total) else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{cfg['shape']} synthetic: {N} x {D} fp32 {('cosine', 'dot', 'L2')[METRIC]} per GPU ({'clustered, ' + str(cfg['centres']) + ' Gaussian centres' if cfg['centres'] else 'uniform(-1, 1) coordinates'}), "
+        "config": {"workload": f"{cfg['shape']} synthetic: {N} x {D} fp32 {('cosine', 'dot', 'L2')[METRIC]} per GPU ({'clustered, ' + str(cfg['centres']) + ' Gaussian centres' if cfg['centres'] else 'uniform coordinates in ' + str(cfg.get('uniform', (-1.0, 1.0)))}), "
                                f"{Q}-query batch, HNSW M={M} ef_construction={EF_BUILD}, top-{K}",
                    "rccl_ranks": world if exchange else 0, "total_rows": N * world,
                    "ef_search": ef, "recall_at_10": sweep[ef]["recall"], "ef_sweep": sweep, "shards": world,
