@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--ef", type=int, default=0, help="0 = sweep and pick the smallest ef with recall >= target")
     ap.add_argument("--target-recall", type=float, default=0.95)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batches", type=int, default=8,
+                    help="distinct query batches the timed steps rotate through (step i searches batch i mod B), so that no step "
+                         "finds the rows of its own previous run in a cache; 1 = replay one batch")
     ap.add_argument("--cpu-queries", type=int, default=0, help="queries of the CPU baseline sample (0 = all for c2, 1000 otherwise)")
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams the timed steps rotate over (consecutive batches overlap, which hides the tail of "
@@ -138,13 +141,14 @@ def main():
     if cfg["centres"]:
         centres = np.random.default_rng(SEED).uniform(0, 128, size=(cfg["centres"], D)).astype(np.float32)
         base = clustered(N, D, SEED + 1 + rank, centres)
-        queries = clustered(Q, D, SEED + 1000, centres)
+        batches = [clustered(Q, D, SEED + 1000 + b, centres) for b in range(max(1, args.batches))]
     else:                                                        # c1: uniform(-1, 1) per coordinate, like generate_points of tests/hnsw.rs:12-26
         lo, hi = cfg.get("uniform", (-1.0, 1.0))
         base = np.random.default_rng(SEED + rank).uniform(lo, hi, size=(N, D)).astype(np.float32)
-        queries = np.random.default_rng(SEED + 1000).uniform(lo, hi, size=(Q, D)).astype(np.float32)
+        batches = [np.random.default_rng(SEED + 1000 + b).uniform(lo, hi, size=(Q, D)).astype(np.float32) for b in range(max(1, args.batches))]
     ids = np.arange(N, dtype=np.uint64) + np.uint64(rank) * np.uint64(N)
-    log(f"data: {N}x{D} base (shard {rank}/{world}), {Q} queries in {time.time()-t0:.1f}s")
+    queries, NB = batches[0], len(batches)
+    log(f"data: {N}x{D} base (shard {rank}/{world}), {NB} batches of {Q} queries in {time.time()-t0:.1f}s")
 
     # ---- build the shard's graph on the GPU (hnsw.rs:119-208 linking rules, batched rounds) ----
     t0 = time.time()
@@ -160,15 +164,15 @@ def main():
 
     # ---- device-resident inputs/outputs ----
     stream = torch.cuda.Stream(device=dev)
-    d_q = torch.from_numpy(queries).to(dev)
+    d_qs = [torch.from_numpy(b).to(dev) for b in batches]
     d_out = torch.zeros(Q * K * 16, dtype=torch.uint8, device=dev)
     d_n = torch.zeros(Q, dtype=torch.int32, device=dev)
     d_stats = torch.zeros(Q * 4, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     sp = stream.cuda_stream
 
-    def search(ef):
-        vdb.check(vdb.fn.index_search_batch_dev(index._h, d_q.data_ptr(), Q, K, ef, d_out.data_ptr(), d_n.data_ptr(), d_stats.data_ptr(), sp))
+    def search(ef, b=0):
+        vdb.check(vdb.fn.index_search_batch_dev(index._h, d_qs[b].data_ptr(), Q, K, ef, d_out.data_ptr(), d_n.data_ptr(), d_stats.data_ptr(), sp))
 
     def fetch():
         stream.synchronize()
@@ -183,31 +187,39 @@ def main():
         return shards.merge_dev(out_t, n_t, Q, K)
 
     # ---- ground truth: exact k-NN on the GPU (strict arithmetic, (key, id) order) ----
-    t0 = time.time()
+    exacts, exact_s = [], 0.0
     e_out = torch.zeros(Q * K * 16, dtype=torch.uint8, device=dev); e_n = torch.zeros(Q, dtype=torch.int32, device=dev)
-    vdb.check(vdb.fn.index_exact_knn_batch_dev(index._h, d_q.data_ptr(), Q, K, e_out.data_ptr(), e_n.data_ptr(), sp))
-    stream.synchronize()
-    exact_s = time.time() - t0
-    torch.cuda.synchronize()
-    ge_out, ge_n = merged(e_out, e_n)
-    torch.cuda.synchronize()
-    exact = ge_out.cpu().numpy().view(vdb.SCORED_DTYPE).reshape(Q, K)
-    log(f"exact k-NN ground truth in {exact_s:.2f}s ({2.0*Q*N*D/exact_s/1e12:.2f} TFLOP/s equivalent)")
+    for b in range(NB):
+        t0 = time.time()
+        vdb.check(vdb.fn.index_exact_knn_batch_dev(index._h, d_qs[b].data_ptr(), Q, K, e_out.data_ptr(), e_n.data_ptr(), sp))
+        stream.synchronize()
+        if b or NB == 1: exact_s += time.time() - t0         # with several batches the first call, which also allocates, is left out
+        torch.cuda.synchronize()
+        ge_out, ge_n = merged(e_out, e_n)
+        torch.cuda.synchronize()
+        exacts.append(ge_out.cpu().numpy().view(vdb.SCORED_DTYPE).reshape(Q, K).copy())
+    exact_s /= max(1, NB - 1)
+    exact = exacts[0]
+    log(f"exact k-NN ground truth: {exact_s:.3f}s per batch ({2.0*Q*N*D/exact_s/1e12:.2f} TFLOP/s equivalent)")
 
     # ---- ef sweep ----
     sweep = {}
     efs = [args.ef] if args.ef else cfg["efs"]
     chosen = None
     for ef in efs:
-        search(ef); stream.synchronize()
-        torch.cuda.synchronize()
-        m_out, m_n = merged(d_out, d_n)
-        torch.cuda.synchronize()
-        ann = m_out.cpu().numpy().view(vdb.SCORED_DTYPE).reshape(Q, K); ann_n = m_n.cpu().numpy().view(np.uint32)
-        st = d_stats.cpu().numpy().view(vdb.STATS_DTYPE).reshape(Q)
-        r = recall_at_k(ann, ann_n, exact, K)
-        sweep[ef] = dict(recall=round(r, 4), rows_scored=float(st["rows_scored"].mean()), overflow=int((st["flags"] & 1).sum()))
-        log(f"  ef={ef}: recall@{K}={r:.4f} rows_scored/query={st['rows_scored'].mean():.0f} max={st['rows_scored'].max()} overflow={sweep[ef]['overflow']}")
+        per_batch, rows, rows_max, overflow = [], [], 0, 0
+        for b in range(NB):                                   # the recall of every batch the timed steps will search
+            search(ef, b); stream.synchronize()
+            torch.cuda.synchronize()
+            m_out, m_n = merged(d_out, d_n)
+            torch.cuda.synchronize()
+            ann = m_out.cpu().numpy().view(vdb.SCORED_DTYPE).reshape(Q, K); ann_n = m_n.cpu().numpy().view(np.uint32)
+            st = d_stats.cpu().numpy().view(vdb.STATS_DTYPE).reshape(Q)
+            per_batch.append(recall_at_k(ann, ann_n, exacts[b], K)); rows.append(float(st["rows_scored"].mean()))
+            rows_max = max(rows_max, int(st["rows_scored"].max())); overflow += int((st["flags"] & 1).sum())
+        r = float(np.mean(per_batch))
+        sweep[ef] = dict(recall=round(r, 4), recall_per_batch=[round(x, 4) for x in per_batch], rows_scored=float(np.mean(rows)), overflow=overflow)
+        log(f"  ef={ef}: recall@{K}={r:.4f} (batches {min(per_batch):.4f} .. {max(per_batch):.4f}) rows_scored/query={np.mean(rows):.0f} max={rows_max} overflow={overflow}")
         if chosen is None and r >= args.target_recall:
             chosen = ef
             if not args.ef:
@@ -230,16 +242,16 @@ def main():
     searched = [torch.cuda.Event() for _ in lanes]      # search of the lane's current step is enqueued
     merged_ev = [None for _ in lanes]                   # the exchange that last read the lane's buffers
 
-    def launch(lane):
+    def launch(lane, b):
         st_, o_, n_, s_ = lane
-        vdb.check(vdb.fn.index_search_batch_dev(index._h, d_q.data_ptr(), Q, K, ef, o_.data_ptr(), n_.data_ptr(), s_.data_ptr(), st_.cuda_stream))
+        vdb.check(vdb.fn.index_search_batch_dev(index._h, d_qs[b].data_ptr(), Q, K, ef, o_.data_ptr(), n_.data_ptr(), s_.data_ptr(), st_.cuda_stream))
 
-    def one_step(i):
+    def one_step(i, replay=False):
         li = i % n_streams
         lane = lanes[li]
         if exchange and merged_ev[li] is not None:
             lane[0].wait_event(merged_ev[li])           # the previous exchange has consumed these buffers
-        launch(lane)
+        launch(lane, 0 if replay else i % NB)
         if exchange:
             # exchange + merge on torch's current stream, ordered after this lane's search by an
             # event (no host synchronisation): the next step's search overlaps it on the other lane
@@ -250,33 +262,42 @@ def main():
             merged_ev[li] = torch.cuda.Event(); merged_ev[li].record(cur)
 
     # (A) back to back on ONE stream, HIP events on that stream: the kernel's own average duration
-    for i in range(args.warmup):
-        launch(lanes[0])
-    barrier()
-    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
-    ev0.record(stream)
-    for _ in range(args.steps):
-        launch(lanes[0])
-    ev1.record(stream)
-    barrier()
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+    def lone(replay):
+        for i in range(args.warmup):
+            launch(lanes[0], 0 if replay else i % NB)
+        barrier()
+        ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+        ev0.record(stream)
+        for i in range(args.steps):
+            launch(lanes[0], 0 if replay else (args.warmup + i) % NB)
+        ev1.record(stream)
+        barrier()
+        return ev0.elapsed_time(ev1) / args.steps
+    kernel_ms = lone(False)
+    kernel_ms_replayed = lone(True) if NB > 1 else kernel_ms
 
-    # (B) the timed K steps: whole-job throughput, steps rotating over the streams
-    for i in range(args.warmup):
-        one_step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(i)
-    barrier()
-    wall = time.perf_counter() - t0
-    if exchange:
-        tt = torch.tensor([wall], dtype=torch.float64, device="cpu" if rehearsal else dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall = float(tt.item())
+    # (B) the timed K steps: whole-job throughput, steps rotating over the streams and over the query batches
+    def timed(replay):
+        for i in range(args.warmup):
+            one_step(i, replay)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            one_step(args.warmup + i, replay)
+        barrier()
+        wall = time.perf_counter() - t0
+        if exchange:
+            tt = torch.tensor([wall], dtype=torch.float64, device="cpu" if rehearsal else dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            wall = float(tt.item())
+        return wall
+    wall = timed(False)
+    wall_replayed = timed(True) if NB > 1 else wall
     ms_per_step = wall * 1e3 / args.steps
     value = world * Q * args.steps / wall
 
+    barrier()
+    search(ef, 0)
     out, out_n, st = fetch()
     result = {
         "metric": cfg["metric_name"], "value": value, "unit": "queries/s",
@@ -285,7 +306,10 @@ def main():
         "config": {"workload": f"{cfg['shape']} synthetic: {N} x {D} fp32 {('cosine', 'dot', 'L2')[METRIC]} per GPU ({'clustered, ' + str(cfg['centres']) + ' Gaussian centres' if cfg['centres'] else 'uniform coordinates in ' + str(cfg.get('uniform', (-1.0, 1.0)))}), "
                                f"{Q}-query batch, HNSW M={M} ef_construction={EF_BUILD}, top-{K}",
                    "rccl_ranks": world if exchange else 0, "total_rows": N * world,
-                   "ef_search": ef, "recall_at_10": sweep[ef]["recall"], "ef_sweep": sweep, "shards": world,
+                   "ef_search": ef, "recall_at_10": sweep[ef]["recall"], "recall_at_10_per_batch": sweep[ef]["recall_per_batch"],
+                   "query_batches": NB, "batch_note": f"step i searches batch i mod {NB}: {NB} distinct {Q}-query batches from the same generator, recall checked on each",
+                   "replayed_batch_qps": world * Q * args.steps / wall_replayed, "replayed_single_stream_ms_per_launch": kernel_ms_replayed,
+                   "ef_sweep": sweep, "shards": world,
                    "unit_note": f"one unit = one query searched against one {N}-vector shard",
                    "merged_queries_per_s": Q * args.steps / wall, "build_seconds": round(build_s, 1),
                    "exact_knn_seconds": round(exact_s, 3), "arith": "fast", "streams": n_streams,
@@ -307,7 +331,11 @@ def main():
         t0 = time.perf_counter()
         ref, refn, rst = ho.search_batch(queries[:nqc], K, ef_search=ef, with_stats=True)
         cpu_s = time.perf_counter() - t0
-        bytes_q = rst["rows_scored"].astype(np.float64) * (4 * info["row_stride_floats"]) + rst["adj_entries"].astype(np.float64) * 4 + rst["expanded"].astype(np.float64) * 8
+        bytes_of = lambda c: c["rows_scored"].astype(np.float64) * (4 * info["row_stride_floats"]) + c["adj_entries"].astype(np.float64) * 4 + c["expanded"].astype(np.float64) * 8
+        bytes_q = bytes_of(rst)
+        if NB > 1:                                              # the sequential algorithm's work over every batch of the rotation
+            ora.set_threads(min(os.cpu_count() or 1, 16))
+            bytes_q = np.concatenate([bytes_q] + [bytes_of(ho.search_batch(batches[b][:nqc], K, ef_search=ef, with_stats=True)[2]) for b in range(1, NB)])
         alg_bytes = float(bytes_q.mean()) * Q
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC passes of tools/collect_profiles.sh: reported only when they were measured on
@@ -330,6 +358,7 @@ def main():
                               "achieved_overlapped": achieved_overlapped, "frac_overlapped": achieved_overlapped / HBM_PEAK_GBS,
                               "ms_per_step_overlapped": ms_per_step, "streams": n_streams,
                               "traffic_frac_of_peak_overlapped": (traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                              "kernel_ms_replayed_batch": kernel_ms_replayed,
                               "algorithmic_bytes_per_query": float(bytes_q.mean()), "rows_scored_per_query": float(rst["rows_scored"].mean()),
                               "gpu_rows_scored_per_query": float(st["rows_scored"].mean())}
         # parity on the bench workload itself: same graph, same queries, same ef
