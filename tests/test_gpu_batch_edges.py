@@ -17,14 +17,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def _pair(vdb, ora, metric, n, d, seed, m=8, ef=32, arith=None):
+def _pair(vdb, ora, metric, n, d, seed, m=8, ef=32, arith=None, **kw):
     """The same graph in the oracle and in the library (built by the oracle, imported)."""
     rng = np.random.default_rng(seed)
     x = rng.normal(size=(n, d)).astype(np.float32)
     ho = ora.HNSWIndex(metric, m, ef, 8, d, seed=seed)
     for i in range(n):
         ho.insert(i + 1, x[i])
-    hp = vdb.HNSWIndex(metric, m, ef, 8, d, seed=seed, arith=arith if arith is not None else vdb.Arith.Strict)
+    hp = vdb.HNSWIndex(metric, m, ef, 8, d, seed=seed, arith=arith if arith is not None else vdb.Arith.Strict, **kw)
     hp.import_graph(ho.export_graph())
     return ho, hp, x, rng
 
@@ -85,8 +85,9 @@ def test_wrong_query_length_and_the_largest_dimension(vdb, ora):
     with pytest.raises(vdb.DBError) as e:
         h.search_batch(np.zeros((2, 15), np.float32), 3)
     assert "mismatch" in str(e.value).lower()                          # hnsw.rs:519-524
-    # 2048 floats per row is the longest the FAST kernels take; the oracle's answer on the same graph
-    ho, hp, x, rng = _pair(vdb, ora, 1, 200, 2048, 77, arith=vdb.Arith.Fast)
+    # 2048 floats per row is the longest the FAST kernels take; the oracle's answer on the same graph (one node per
+    # step: the reference's order of expansion)
+    ho, hp, x, rng = _pair(vdb, ora, 1, 200, 2048, 77, arith=vdb.Arith.Fast, beam_width=1)
     q = rng.normal(size=(6, 2048)).astype(np.float32)
     out, cnt = hp.search_batch(q, 5)
     ref, refn = ho.search_batch(q, 5)

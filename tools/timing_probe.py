@@ -33,6 +33,9 @@ print("start-time deciles (us):", np.percentile(start, [0,10,50,90,99,100]).roun
 ph = out.view(np.uint8).reshape(nq, -1)[:, :80].copy().view(np.uint64).astype(np.float64)
 names = ["select", "adjacency wait", "compaction", "score(gather)", "merge", "-", "bucket read+classify", "CAS", "resolve+slow path", "-"]
 print(f"before the beam (query load, upper-layer descent): mean {ph[:, 9].mean()*0.01:.1f} us of {ph[:, 5].mean()*0.01:.1f} us per query")
+if os.environ.get("VDB_TIMING_SCORE"):
+    print(f"team, wavefront 0: candidates per step-round {ph[:, 8].sum() / np.maximum(st['expanded'].sum() / 4, 1):.1f} (per 4 expansions); row wait {ph[:, 6].sum()/st['expanded'].sum():.0f} cycles/expansion, scoring arithmetic {ph[:, 7].sum()/st['expanded'].sum():.0f}")
+    ph[:, 3] -= ph[:, 6] + ph[:, 7]; ph[:, 8] = 0
 ph[:, 9] = 0; ph[:, 5] = 0
 tot = ph.sum(axis=1)
 print("phase shares of beam cycles (mean over queries):")

@@ -537,6 +537,17 @@ void vdb_index::run_search(SearchArgs a, size_t nq, hipStream_t s, bool retry_on
     while (a.tag_log2 < 15 && ((uint64_t)a.g.n >> (a.tag_log2 + 13)) != 0) ++a.tag_log2;
     if (forced_tags >= 7 && forced_tags <= 15) a.tag_log2 = (uint32_t)forced_tags;      // tests shrink it to force forgetting
     if (const char* fg = getenv("VDB_FORCE_GENERIC")) { if (atoi(fg) != 0) a.force_generic = 1; }   // tests: the LDS-list kernel for every mode
+    // Launches too small to fill the chip with one wavefront per query walk on a team of wavefronts per query.  A step
+    // then expands four nodes per wavefront unless the index (or VDB_BEAM_WIDTH) names a width: that width is the total.
+    a.team = team_size_for(a);
+    if (a.team) {
+        int w = opts.beam_width;
+        if (const char* e = std::getenv("VDB_BEAM_WIDTH")) w = std::atoi(e);
+        a.team_width = w > 0 ? (uint32_t)std::min<int>(w, 4 * (int)a.team) : 4u * a.team;
+        if (const char* e = std::getenv("VDB_TEAM_WIDTH")) { const int t = std::atoi(e); if (t > 0) a.team_width = (uint32_t)std::min<int>(t, 4 * (int)a.team); }
+        // the team shares one visited table: 8192 tags, 16 KiB (fewer ids forgotten and scored again)
+        if (!(forced_tags >= 7 && forced_tags <= 15)) a.tag_log2 = std::max<uint32_t>(a.tag_log2, 13u);
+    }
     if (a.mode == MODE_LITERAL) {
         // the literal walk visits every reachable row: one spill table per query of the launch, sized for all rows
         // (a pool of its own: the geometry differs from the shared one and follows the segment's size)

@@ -12,6 +12,16 @@ void launch_search_plain(const SearchArgs& a, size_t lds, hipStream_t st);
 void launch_search_build(const SearchArgs& a, size_t lds, hipStream_t st);
 void launch_search_masked(const SearchArgs& a, size_t lds, hipStream_t st);
 void launch_search_literal(const SearchArgs& a, size_t lds, hipStream_t st);
+void launch_search_team_cosine(const SearchArgs& a, hipStream_t st);
+void launch_search_team_dot(const SearchArgs& a, hipStream_t st);
+void launch_search_team_euclidean(const SearchArgs& a, hipStream_t st);
+
+uint32_t team_size_for(const SearchArgs& a) {
+    if (a.mode != MODE_SEARCH || reg_list_chunks(a) == 0 || !a.g.ublk) return 0;
+    if (const char* e = std::getenv("VDB_TEAM")) { const int t = std::atoi(e); return t == 2 || t == 4 ? (uint32_t)t : 0u; }
+    // 1024 SIMDs hold four wavefronts each at the register budget of these kernels
+    return a.nq <= 1024 ? 4u : a.nq <= 2048 ? 2u : 0u;
+}
 
 size_t search_lds_bytes(const SearchArgs& a) {
     const size_t ef_cap = (a.ef + 63u) & ~63u;
@@ -25,6 +35,15 @@ size_t search_lds_bytes(const SearchArgs& a) {
 
 void launch_search(const SearchArgs& a, hipStream_t st) {
     if (a.nq == 0) return;
+    if (a.team) {
+        switch (a.g.metric) {
+            case VDB_COSINE: launch_search_team_cosine(a, st); break;
+            case VDB_DOT: launch_search_team_dot(a, st); break;
+            default: launch_search_team_euclidean(a, st); break;
+        }
+        VDB_HIP(hipGetLastError());
+        return;
+    }
     const size_t lds = search_lds_bytes(a);
     if (lds > 160 * 1024) throw Failure(err_arg("search working set exceeds the 160 KiB LDS of a CU"));
     switch (a.mode) {

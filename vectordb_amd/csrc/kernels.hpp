@@ -51,6 +51,8 @@ struct SearchArgs {
     uint32_t ef, top_k;
     uint32_t beam_width;         // register-resident beam: nodes expanded per step (1..4)
     uint32_t force_generic;      // 1: LDS-resident list with HBM spill tables even where the register beam applies
+    uint32_t team;               // 0: one wavefront per query; 2 / 4: a team of that many wavefronts per query (search_team.hpp)
+    uint32_t team_width;         // team: nodes expanded per step in total (1 .. 4 x team)
     vdb_scored_point* out;       // nq x top_k
     uint32_t* out_n;             // nq
     vdb_query_stats* stats;      // nq or nullptr
@@ -89,6 +91,9 @@ inline uint32_t reg_list_chunks(const SearchArgs& a) {
 }
 
 void launch_search(const SearchArgs& a, hipStream_t s);
+// Wavefronts per query a launch of nq unfiltered FAST searches takes (0 = one): small launches cannot fill the chip
+// with one wavefront per query and run each walk on a team instead.
+uint32_t team_size_for(const SearchArgs& a);
 size_t search_lds_bytes(const SearchArgs& a);
 
 // out[q * n + i] = score(queries[q], base[i]); queries nq x dim (dense), base rows at `stride`.

@@ -358,6 +358,10 @@ struct Searcher {
                     }
                 }
             }
+#ifdef VDB_TIMING_SCORE   // diagnostic build: row wait and arithmetic of the scoring apart (phases 6 and 7)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            VDB_T_MARK(6);
+#endif
 #pragma unroll
             for (int p = 0; p < PP; ++p) {
                 if (p == 0 || base + p * RPP < m) {
@@ -386,6 +390,9 @@ struct Searcher {
                     if (g == 0 && ci < m) craw[ci] = raw;
                 }
             }
+#ifdef VDB_TIMING_SCORE
+            VDB_T_MARK(7);
+#endif
         }
         wave_sync();
     }
@@ -663,9 +670,21 @@ struct Searcher {
                         const uint2 e = perm[c * WAVE + lane];
                         rk[c] = __uint_as_float(e.x); rv[c] = e.y;
                     }
+                    if (NCC > 4) {
+                        // lists of six and eight chunks also serve ef values that end one chunk earlier
+                        float wk = INF;
+#pragma unroll
+                        for (int c = NCC - 2; c < NCC; ++c) {
+                            if ((uint32_t)(c * WAVE + lane) >= cap) { rk[c] = INF; rv[c] = FLAG_EXPANDED; }
+                            if ((uint32_t)c == ((cap - 1) >> 6)) wk = rk[c];
+                        }
+                        wave_sync();
+                        worst = (n >= cap) ? readlane_f(wk, (int)((cap - 1) & 63u)) : INF;
+                    } else {
                     if ((uint32_t)((NCC - 1) * WAVE + lane) >= cap) { rk[NCC - 1] = INF; rv[NCC - 1] = FLAG_EXPANDED; }
                     wave_sync();
                     worst = (n >= cap) ? readlane_f(rk[NCC - 1], (int)((cap - 1) & 63u)) : INF;
+                    }
                 }
                 VDB_T_MARK(4);
             }
