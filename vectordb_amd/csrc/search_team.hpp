@@ -5,8 +5,8 @@
 // Wavefront 0 owns the ascending result list in its registers, picks the parents of a step and merges the candidates.
 // Every wavefront of the team takes a share of the step's parents (parent i goes to wavefront i mod TW): it fetches
 // their adjacency blocks, tests their neighbours against the visited table the team shares in LDS, scores the unvisited
-// rows and leaves (slot, score) in its own LDS segment.  Two workgroup barriers per step: parents published /
-// candidates published.  A step expands up to 4 x TW nodes; expanding w nodes per step in total is the same walk as the
+// rows' slots into a pool in LDS; every wavefront then scores an equal share of the pool and wavefront 0 merges it.
+// Four workgroup barriers per step: parents / counts / pool / scores published.  A step expands up to 4 x TW nodes; expanding w nodes per step in total is the same walk as the
 // one-wavefront beam at width w (the candidates of a step reach the list in wavefront order instead of parent order,
 // which only orders exactly equal keys differently).
 // The upper-layer descent makes the same moves as greedy_fused(): every wavefront reads the current node's block, the
@@ -198,6 +198,8 @@ struct TeamSearcher : Searcher<MODE_SEARCH, G, CH, PASSES, false, METRIC, NC> {
         float worst = INF;
         if (width > (uint32_t)(EMAX * TW)) width = EMAX * TW;
         if (width == 0) width = 1;
+        // the beam's candidates live in one pool shared by the team: TW * SEG slots followed by as many scores
+        cand = segs; craw = reinterpret_cast<float*>(segs + (size_t)TW * SEG);
         if (wv == 0) {
             uint32_t start = entry;
             if (B::is_deleted(entry) && a.fallback_live != NONE32) start = a.fallback_live;      // hnsw.rs:440-444
@@ -246,10 +248,12 @@ struct TeamSearcher : Searcher<MODE_SEARCH, G, CH, PASSES, false, METRIC, NC> {
             }
             uint32_t hub_e = 0, hub_ch = 1, hub_left = 0;
             int m = 0;
+            uint32_t nb[EMAX];
+            bool fresh[EMAX];
             {   // ---- the inline neighbours (block words 1..62) of this wavefront's parents at once ----
-                uint32_t nb[EMAX], w0[EMAX], tag[EMAX], widx[EMAX], expect[EMAX], desired[EMAX], old[EMAX], half[EMAX];
+                uint32_t w0[EMAX], tag[EMAX], widx[EMAX], expect[EMAX], desired[EMAX], old[EMAX], half[EMAX];
                 uint2 bk[EMAX];
-                bool tr[EMAX], fresh[EMAX], slow[EMAX], full_b[EMAX];
+                bool tr[EMAX], slow[EMAX], full_b[EMAX];
 #pragma unroll
                 for (int e = 0; e < EMAX; ++e) {
                     nb[e] = w[e];
@@ -296,49 +300,59 @@ struct TeamSearcher : Searcher<MODE_SEARCH, G, CH, PASSES, false, METRIC, NC> {
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < EMAX; ++e) {
-                    const uint64_t mk = ballot(fresh[e]);
-                    if (fresh[e]) cand[m + rank_below(mk)] = nb[e];
-                    m += popc64(mk);
-                }
+                for (int e = 0; e < EMAX; ++e) m += popc64(ballot(fresh[e]));
             }
             VDB_T_MARK(1);
-#ifdef VDB_TIMING_SCORE
-            B::tacc[8] += (unsigned long long)m;        // candidates of wavefront 0 in round 0
-#endif
+            // ---- rounds of the step: the team's unvisited neighbours go into one pool (wavefront order, then parent
+            // order, then list order), every wavefront scores an equal share of it, wavefront 0 merges it ----
             for (;;) {
-                if (m) {
-                    rows_scored += m;
-                    wave_sync();
-                    if (full) B::template score_rows<true>(m); else B::template score_rows<false>(m);
-                }
-                VDB_T_MARK(3);
                 if (lane == 0) { ctl->cnt[wv] = (uint32_t)m; ctl->hub[wv] = hub_left; if (forgot) ctl->forgot = 1u; }
-                __syncthreads();                                          // candidates published
-                VDB_T_MARK(2);
-                uint32_t total_hub = 0;
+                __syncthreads();                                          // counts published
+                uint32_t total_hub = 0, off = 0, total = 0;
 #pragma unroll
-                for (int t = 0; t < TW; ++t) total_hub += ctl->hub[t];
-                if (wv == 0) {
-                    forgot = forgot | (ctl->forgot != 0u);
-#pragma unroll 1
-                    for (int t = 0; t < TW; ++t) {
-                        const int mt = (int)ctl->cnt[t];
-                        const uint32_t* ct = segs + (size_t)t * SEG * 2;
-                        const float* kt = reinterpret_cast<const float*>(ct + SEG);
-                        for (int base = 0; base < mt; base += WAVE) {
+                for (int t = 0; t < TW; ++t) {
+                    const uint32_t ct = ctl->cnt[t];
+                    total_hub += ctl->hub[t];
+                    off += t < wv ? ct : 0u;
+                    total += ct;
+                }
+                if (total) {
+                    uint32_t pos = off;
+#pragma unroll
+                    for (int e = 0; e < EMAX; ++e) {
+                        const uint64_t mk = ballot(fresh[e]);
+                        if (fresh[e]) cand[pos + rank_below(mk)] = nb[e];
+                        pos += popc64(mk);
+                    }
+                    __syncthreads();                                      // the pool is complete
+                    const int per = (int)((total + TW - 1) / TW), lo = wv * per;
+                    const int cnt = lo < (int)total ? ((int)total - lo < per ? (int)total - lo : per) : 0;
+                    if (cnt > 0) {
+                        rows_scored += cnt;
+                        cand += lo; craw += lo;
+                        if (full) B::template score_rows<true>(cnt); else B::template score_rows<false>(cnt);
+                        cand -= lo; craw -= lo;
+                    }
+                    VDB_T_MARK(3);
+                    __syncthreads();                                      // scores published
+                    VDB_T_MARK(2);
+                    if (wv == 0) {
+                        forgot = forgot | (ctl->forgot != 0u);
+                        for (int base = 0; base < (int)total; base += WAVE) {
                             const int j = base + lane;
-                            const bool have = j < mt;
-                            const float kj = have ? B::key_of(kt[j]) : INF;
-                            const uint32_t sj = have ? ct[j] : 0u;
+                            const bool have = j < (int)total;
+                            const float kj = have ? B::key_of(craw[j]) : INF;
+                            const uint32_t sj = have ? cand[j] : 0u;
                             merge_block(have, kj, sj, rk, rv, n, worst, cap, forgot);
                         }
                     }
+                    VDB_T_MARK(4);
                 }
-                VDB_T_MARK(4);
                 if (total_hub == 0) break;
-                __syncthreads();                                          // the merge has read every segment
+                if (total) __syncthreads();                               // the merge has read the pool
                 m = 0;
+#pragma unroll
+                for (int e = 0; e < EMAX; ++e) fresh[e] = false;
                 if (hub_left) {                                           // one overflow chunk of a high-degree parent
                     --hub_left;
                     Adj A;
@@ -350,17 +364,16 @@ struct TeamSearcher : Searcher<MODE_SEARCH, G, CH, PASSES, false, METRIC, NC> {
                         if (hub_ch < A.chunks()) break;
                         ++hub_e; hub_ch = 1;
                     }
-                    uint32_t nb;
-                    const bool in = A.get(hub_ch, nb);
+                    uint32_t nbh;
+                    const bool in = A.get(hub_ch, nbh);
                     ++hub_ch;
-                    bool fresh = in && !B::is_deleted(nb);
+                    bool fr = in && !B::is_deleted(nbh);
                     int r = 0;
-                    if (fresh) r = ts.insert(nb);
-                    fresh = r != 0;
+                    if (fr) r = ts.insert(nbh);
+                    fr = r != 0;
                     forgot = forgot | (ballot(r == 2) != 0);
-                    const uint64_t mk = ballot(fresh);
-                    if (fresh) cand[rank_below(mk)] = nb;
-                    m = popc64(mk);
+                    nb[0] = nbh; fresh[0] = fr;
+                    m = popc64(ballot(fr));
                 }
             }
         }
