@@ -578,7 +578,7 @@ void vdb_index::run_search(SearchArgs a, size_t nq, hipStream_t s, bool retry_on
     if (reg_list_chunks(a) > 0 && a.mode != MODE_BUILD) return;
     if (!retry_on_overflow) return;
     std::vector<vdb_query_stats> st(nq);
-    VDB_HIP(hipMemcpyAsync(st.data(), a.stats, nq * sizeof(vdb_query_stats), hipMemcpyDeviceToHost, s));
+    VDB_HIP(hipMemcpyAsync(st.data(), a.stats, nq * sizeof(vdb_query_stats), hipMemcpyDefault, s));   // a.stats may be pinned host memory (small batches)
     VDB_HIP(hipStreamSynchronize(s));
     std::vector<uint32_t> redo;
     for (size_t i = 0; i < nq; ++i) if (st[i].flags & QF_HASH_OVERFLOW) redo.push_back((uint32_t)i);
@@ -599,7 +599,7 @@ void vdb_index::run_search(SearchArgs a, size_t nq, hipStream_t s, bool retry_on
             b.out = a.out ? a.out + (size_t)qi * a.top_k : nullptr; b.out_n = a.out_n + qi; b.stats = a.stats + qi;
             launch_search(b, s);
         }
-        VDB_HIP(hipMemcpyAsync(st.data(), a.stats, nq * sizeof(vdb_query_stats), hipMemcpyDeviceToHost, s));
+        VDB_HIP(hipMemcpyAsync(st.data(), a.stats, nq * sizeof(vdb_query_stats), hipMemcpyDefault, s));   // a.stats may be pinned host memory (small batches)
         VDB_HIP(hipStreamSynchronize(s));
         std::vector<uint32_t> again;
         for (uint32_t qi : redo) if (st[qi].flags & QF_HASH_OVERFLOW) again.push_back(qi);
@@ -626,15 +626,22 @@ void vdb_index::search_batch(const float* q, size_t nq, size_t top_k, size_t ef_
     // small batches go through pinned host memory: copies from and to pageable memory cost more than the search of one query
     const size_t b_q = nq * dim * sizeof(float), b_out = nq * top_k * sizeof(vdb_scored_point), b_n = nq * sizeof(uint32_t), b_st = nq * sizeof(vdb_query_stats);
     const bool small = b_q + b_out + b_n + b_st <= (size_t(1) << 20);
-    char* pin = small ? static_cast<char*>(pinned(b_q + b_out + b_n + b_st)) : nullptr;
-    if (small) { std::memcpy(pin, q, b_q); VDB_HIP(hipMemcpyAsync(s_q.p, pin, b_q, hipMemcpyHostToDevice, stream)); }
+    // a handful of queries (one per call is the reference's shape): the kernel reads them from pinned host memory and writes
+    // its results there, so the call is one launch and one wait — no copy is enqueued at all
+    const size_t o_out = (b_q + 15) & ~size_t(15), o_n = o_out + ((b_out + 15) & ~size_t(15)), o_st = o_n + ((b_n + 15) & ~size_t(15));
+    const bool zero = small && o_st + b_st <= (size_t(64) << 10) && fa.mode != MODE_LITERAL && !std::getenv("VDB_NO_ZERO_COPY");
+    char* pin = small ? static_cast<char*>(pinned(zero ? o_st + b_st : b_q + b_out + b_n + b_st)) : nullptr;
+    char* dpin = nullptr;
+    if (zero) { std::memcpy(pin, q, b_q); VDB_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&dpin), pin, 0)); }
+    else if (small) { std::memcpy(pin, q, b_q); VDB_HIP(hipMemcpyAsync(s_q.p, pin, b_q, hipMemcpyHostToDevice, stream)); }
     else VDB_HIP(hipMemcpyAsync(s_q.p, q, nq * dim * sizeof(float), hipMemcpyHostToDevice, stream));
     SearchArgs a{};
-    a.g = view(); a.mode = fa.mode; a.arith = opts.arith; a.queries = s_q.p; a.nq = (uint32_t)nq;
+    a.g = view(); a.mode = fa.mode; a.arith = opts.arith; a.queries = zero ? reinterpret_cast<const float*>(dpin) : s_q.p; a.nq = (uint32_t)nq;
     a.entry = fa.entry_slot != NONE32 ? fa.entry_slot : slot_of.at(*entry_point);
     a.max_level = (uint32_t)current_max_level;
     auto fl = first_live_slot(); a.fallback_live = fl ? *fl : NONE32;
     a.ef = (uint32_t)ef_; a.top_k = (uint32_t)top_k; a.out = s_out.p; a.out_n = s_n.p; a.stats = s_stats.p;
+    if (zero) { a.out = reinterpret_cast<vdb_scored_point*>(dpin + o_out); a.out_n = reinterpret_cast<uint32_t*>(dpin + o_n); a.stats = reinterpret_cast<vdb_query_stats*>(dpin + o_st); }
     a.beam_width = beam_width();
     if (fa.bits) { a.pass_bits = fa.bits->d_pass.p; a.err_bits = fa.bits->d_err.p; }
     if (fa.mode == MODE_LITERAL) {
@@ -658,9 +665,12 @@ void vdb_index::search_batch(const float* q, size_t nq, size_t top_k, size_t ef_
             run_search(b, b.nq, stream, true, b.queries);
         }
     } else
-    run_search(a, nq, stream, true, s_q.p);
+    run_search(a, nq, stream, true, a.queries);
     std::vector<vdb_query_stats> st(nq);
-    if (small) {
+    if (zero) {
+        VDB_HIP(hipStreamSynchronize(stream));
+        std::memcpy(out, pin + o_out, b_out); std::memcpy(out_n, pin + o_n, b_n); std::memcpy(st.data(), pin + o_st, b_st);
+    } else if (small) {
         VDB_HIP(hipMemcpyAsync(pin + b_q, s_out.p, b_out, hipMemcpyDeviceToHost, stream));
         VDB_HIP(hipMemcpyAsync(pin + b_q + b_out, s_n.p, b_n, hipMemcpyDeviceToHost, stream));
         VDB_HIP(hipMemcpyAsync(pin + b_q + b_out + b_n, s_stats.p, b_st, hipMemcpyDeviceToHost, stream));
