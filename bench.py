@@ -305,7 +305,7 @@ def main():
         "higher_is_better": True, "scaling": "strong" if (args.config == "c5" and args.c5_total) else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{cfg['shape']} synthetic: {N} x {D} fp32 {('cosine', 'dot', 'L2')[METRIC]} per GPU ({'clustered, ' + str(cfg['centres']) + ' Gaussian centres' if cfg['centres'] else 'uniform coordinates in ' + str(cfg.get('uniform', (-1.0, 1.0)))}), "
                                f"{Q}-query batch, HNSW M={M} ef_construction={EF_BUILD}, top-{K}",
-                   "rccl_ranks": world if exchange else 0, "total_rows": N * world,
+                   "rccl_ranks": shards.rccl_ranks(), "total_rows": N * world,
                    "ef_search": ef, "recall_at_10": sweep[ef]["recall"], "recall_at_10_per_batch": sweep[ef]["recall_per_batch"],
                    "query_batches": NB, "batch_note": f"step i searches batch i mod {NB}: {NB} distinct {Q}-query batches from the same generator, recall checked on each",
                    "replayed_batch_qps": world * Q * args.steps / wall_replayed, "replayed_single_stream_ms_per_launch": kernel_ms_replayed,

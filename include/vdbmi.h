@@ -380,6 +380,37 @@ vdb_status vdb_segment_filter_bitmaps(const vdb_segment* s, const vdb_filter* f,
 vdb_status vdb_topk_merge_dev(const vdb_scored_point* d_lists, const uint32_t* d_counts, size_t n_shards,
                               size_t nq, size_t k, vdb_scored_point* d_out, uint32_t* d_out_n, void* stream);
 
+/* Sharded search (extension; the reference holds ONE in-memory segment, src/segment/segment.rs:11-18, and has no
+ * distributed layer).  The base set is split into contiguous id ranges, one shard (an index or a segment with its own
+ * graph) per rank and GPU.  A group is one RCCL communicator over the ranks; every rank searches the full query batch
+ * against its shard, the per-shard top-k rows are exchanged with one all-gather (records, then counts) on the caller's
+ * stream and merged by (sort_key asc, id asc) on every rank, so every rank receives the same nq x top_k rows.
+ *
+ * vdb_shard_group_unique_id: rank 0 draws the communicator's id (ncclUniqueId, 128 bytes) and hands it to the other
+ * ranks by whatever channel launched them; vdb_shard_group_new is collective over the ranks (ncclCommInitRank) and
+ * binds the calling rank to `device`.  Calls on one group are serialised (its staging buffers are shared); use one
+ * group per stream to overlap exchanges.  vdb_shard_group_size / _rank report what the communicator itself says. */
+typedef struct vdb_shard_group vdb_shard_group;
+vdb_status vdb_shard_group_unique_id(void* out, size_t cap);
+vdb_status vdb_shard_group_new(const void* unique_id, size_t id_bytes, int rank, int world, int device, vdb_shard_group** out);
+void vdb_shard_group_free(vdb_shard_group* g);
+int vdb_shard_group_size(const vdb_shard_group* g);
+int vdb_shard_group_rank(const vdb_shard_group* g);
+/* All-gather + merge of rows this rank has already computed (d_lists: nq x k, d_counts: nq). */
+vdb_status vdb_shard_exchange_dev(vdb_shard_group* g, const vdb_scored_point* d_lists, const uint32_t* d_counts, size_t nq, size_t k,
+                                  vdb_scored_point* d_out, uint32_t* d_out_n, void* stream);
+/* HNSWIndex::search (hnsw.rs:513-554) over every shard: vdb_index_search_batch_dev on this rank's index, then the exchange. */
+vdb_status vdb_shard_search_batch_dev(vdb_shard_group* g, const vdb_index* x, const float* d_q, size_t nq, size_t top_k, size_t ef_search,
+                                      vdb_scored_point* d_out, uint32_t* d_out_n, void* stream);
+/* Exact k-NN over every shard: the merged rows equal the exact k-NN of the whole set. */
+vdb_status vdb_shard_exact_knn_batch_dev(vdb_shard_group* g, const vdb_index* x, const float* d_q, size_t nq, size_t top_k,
+                                         vdb_scored_point* d_out, uint32_t* d_out_n, void* stream);
+/* Segment::search / search_with_filter (segment.rs:103-147) over every shard: each rank's segment owns its slice of
+ * the payloads, of every filter bitmap and of the tombstones; `f` may be NULL.  A shard without live points
+ * contributes no rows (for one segment that is SearchError, segment.rs:104-107). */
+vdb_status vdb_shard_segment_search_batch_dev(vdb_shard_group* g, const vdb_segment* s, const float* d_q, size_t nq, size_t top_k,
+                                              size_t ef_search, const vdb_filter* f, vdb_scored_point* d_out, uint32_t* d_out_n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

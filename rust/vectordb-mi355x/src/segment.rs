@@ -94,17 +94,26 @@ pub mod segment {
         }
         pub fn delete(&mut self, point_id: PointId) -> Result<(), DBError> {                                               // segment.rs:71
             if self.deleted.contains(&point_id) || !self.hnsw.contains(&point_id) { return Ok(()); }
-            let before = self.hnsw.len();
+            let old_handle = self.hnsw.h;
             check(unsafe { ffi::vdb_segment_delete(self.s, point_id) })?;
+            // a purge (segment.rs:88-95) replaces and frees the index inside the segment: take the current handle before
+            // anything else goes through it
+            self.hnsw.h = unsafe { ffi::vdb_segment_hnsw_mut(self.s) };
             if let Some(p) = self.payloads.get(&point_id) { self.payload_index.remove(point_id, p); }
             self.deleted.insert(point_id);
-            if self.hnsw.len() < before { self.after_purge(); }                    // the library purged (segment.rs:88-95)
+            let purged = self.hnsw.h != old_handle || unsafe { ffi::vdb_index_contains(self.hnsw.h, point_id) } == 0;
+            if purged { self.after_purge(); }
             Ok(())
         }
         fn after_purge(&mut self) {                                                // segment.rs:166-217: deleted points are gone for good
-            self.hnsw.h = unsafe { ffi::vdb_segment_hnsw_mut(self.s) };            // purge builds a new index inside the segment
             let gone: Vec<PointId> = self.deleted.drain().collect();
             for id in gone { self.payloads.remove(&id); self.hnsw.vectors.remove(&id); }
+            // purge re-inserts the live rows (Cosine rows are normalised again, hnsw.rs:138): refresh the mirrored vectors
+            let dim = unsafe { ffi::vdb_index_dim(self.hnsw.h) };
+            for (id, v) in self.hnsw.vectors.iter_mut() {
+                let mut row = vec![0f32; dim];
+                if unsafe { ffi::vdb_index_get_vector(self.hnsw.h, *id, row.as_mut_ptr(), dim) } == 0 { *v = row; }
+            }
         }
         fn run(&self, call: Call, query: &Vector, top_k: usize, filter: Option<&Filter>) -> Result<Vec<ScoredPoint>, DBError> {
             let c = filter.map(c_filter);

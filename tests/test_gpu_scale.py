@@ -162,3 +162,43 @@ def test_sharded_exchange_on_the_gpu_matches_one_index(vdb, workload):
         both = np.concatenate([a[i][: an[i]], b[i][: bn[i]]])
         o = np.lexsort((both["id"], both["sort_key"]))[:K]
         assert np.array_equal(both[o]["id"], got[i]["id"])
+
+
+def test_shard_group_entry_points_in_a_group_of_one(vdb, workload):
+    """The C-ABI shard group (one RCCL communicator created by the library, no torch.distributed): in a group of one
+    rank the sharded index search, exact k-NN and filtered segment search — local search, all-gather, merge kernel on one
+    stream — return exactly what the unsharded entry points return, and the communicator reports its own size."""
+    torch = pytest.importorskip("torch")
+    from vectordb_amd.sharded import ShardedIndex
+    w = workload
+    n, nq = 30_000, 300
+    base, ids, q = w["base"][:n], w["ids"][:n], w["queries"][:nq]
+    dev = torch.device("cuda", 0)
+    h = vdb.HNSWIndex(vdb.DistanceMetric.Euclidean, 16, 64, 16, D, seed=21); h.insert_batch(ids, base)
+    sh = ShardedIndex(vdb, h, device=dev, always_exchange=True)
+    assert sh.vgroup and sh.rccl_ranks() == 1 and vdb.fn.shard_group_rank(sh.vgroup) == 0
+    dq = torch.from_numpy(q).to(dev)
+    torch.cuda.synchronize()
+    view = lambda o, c: (o.cpu().numpy().view(vdb.SCORED_DTYPE).reshape(nq, K), c.cpu().numpy().view(np.uint32))
+    want, want_n = h.search_batch(q, K, ef_search=96)
+    got, got_n = view(*sh.search_batch_dev(dq, nq, K, ef_search=96)); torch.cuda.synchronize()
+    got, got_n = view(*sh.search_batch_dev(dq, nq, K, ef_search=96))
+    assert np.array_equal(want_n, got_n) and np.array_equal(want, got)
+    want, want_n = h.exact_knn_batch(q, K)
+    got, got_n = view(*sh.exact_knn_batch_dev(dq, nq, K))
+    assert np.array_equal(want_n, got_n) and np.array_equal(want, got)
+    seg = vdb.Segment(vdb.HNSWIndex(vdb.DistanceMetric.Euclidean, 16, 64, 16, D, seed=22, filter_mode=vdb.FilterMode.Masked))
+    sid = seg.insert_batch_columns(base[:8000], {"cat": (np.arange(8000) % 20).astype(np.int64)})
+    for i in range(0, 8000, 37): seg.delete(int(sid[i]))
+    for f in (None, vdb.Filter.Match("cat", vdb.PayloadValue.Int(3)), vdb.Filter.Compare("cat", vdb.ScalarComparisonOp.Lt, vdb.PayloadValue.Int(10))):
+        want, want_n = seg.search_batch(q, K, ef_search=96, filter=f)
+        got, got_n = view(*sh.segment_search_batch_dev(seg, dq, nq, K, ef_search=96, filter=f))
+        assert np.array_equal(want_n, got_n)
+        for i in range(nq): assert np.array_equal(want[i][: want_n[i]], got[i][: got_n[i]])
+    # rows computed elsewhere go through the exchange alone
+    lo = torch.from_numpy(want.view(np.uint8).reshape(-1).copy()).to(dev); lc = torch.from_numpy(want_n.view(np.int32).copy()).to(dev)
+    m_out, m_cnt = sh.merge_dev(lo, lc, nq, K)
+    torch.cuda.synchronize()
+    assert m_out.data_ptr() != lo.data_ptr() and torch.equal(m_cnt, lc)
+    mo = m_out.cpu().numpy().view(vdb.SCORED_DTYPE).reshape(nq, K)
+    for i in range(nq): assert np.array_equal(mo[i][: want_n[i]], want[i][: want_n[i]])

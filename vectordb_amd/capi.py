@@ -203,6 +203,12 @@ _SIGS = {
     "topk_merge_dev": (_I, [_VP, _VP, _SZ, _SZ, _SZ, _VP, _VP, _VP]),
     "score_scan_dev": (_I, [_VP, _SZ, _VP, _SZ, _SZ, _SZ, _I, _I, _VP, _VP]),
     "default_options": (None, [_VP]),
+    "shard_group_unique_id": (_I, [_VP, _SZ]), "shard_group_new": (_I, [_VP, _SZ, _I, _I, _I, C.POINTER(_VP)]),
+    "shard_group_free": (None, [_VP]), "shard_group_size": (_I, [_VP]), "shard_group_rank": (_I, [_VP]),
+    "shard_exchange_dev": (_I, [_VP, _VP, _VP, _SZ, _SZ, _VP, _VP, _VP]),
+    "shard_search_batch_dev": (_I, [_VP, _VP, _VP, _SZ, _SZ, _SZ, _VP, _VP, _VP]),
+    "shard_exact_knn_batch_dev": (_I, [_VP, _VP, _VP, _SZ, _SZ, _VP, _VP, _VP]),
+    "shard_segment_search_batch_dev": (_I, [_VP, _VP, _VP, _SZ, _SZ, _SZ, _VP, _VP, _VP, _VP]),
 }
 # entry points that only some libraries export (host-buffer helpers of the checker)
 _OPTIONAL = {"set_threads": (None, [_I]), "segment_set_filter_mode": (None, [_VP, _I]),

@@ -3,13 +3,17 @@
 The reference holds a single in-memory segment (src/segment/segment.rs:11-18) and has no
 distributed layer; this module is the scaling axis the GPU build adds.  Every rank searches the
 FULL query batch against its shard, the per-shard top-k lists are exchanged with ONE all-gather
-(`torch.distributed`, backend "nccl" = RCCL on the GPU box, "gloo" in CPU tests), and every rank
-merges them by (sort_key ascending, id ascending) — the order `HNSWIndex::search` returns
-(src/vector/hnsw.rs:541-549) with ties broken by id.
+and every rank merges them by (sort_key ascending, id ascending) — the order `HNSWIndex::search`
+returns (src/vector/hnsw.rs:541-549) with ties broken by id.
 
-The merge itself is `vdb_topk_merge_dev` (a GPU kernel).  A backend that exports a host-buffer
-`topk_merge` (only the CPU checker does) is merged through that instead, which is how the
-world_size-2 gloo tests run without a GPU.
+On GPUs the exchange is the library's own: a `vdb_shard_group` (one RCCL communicator, created
+through the C ABI; torch.distributed only carries the communicator's id from rank 0 to the other
+ranks) and `vdb_shard_exchange_dev` / `vdb_shard_search_batch_dev` / `vdb_shard_exact_knn_batch_dev` /
+`vdb_shard_segment_search_batch_dev`, which run the all-gather and the merge kernel on the caller's
+stream.  A host-side process group ("gloo": CPU tests, rehearsals on a one-GPU box) gathers through
+torch.distributed instead and merges with `vdb_topk_merge_dev`; a backend that exports a host-buffer
+`topk_merge` (only the CPU checker does) is merged through that, which is how the world_size-2
+gloo tests run without a GPU.
 """
 from __future__ import annotations
 
@@ -43,9 +47,69 @@ class ShardedIndex:
         self.api, self.index, self.group, self.device = api, index, group, device
         self.always_exchange = always_exchange      # run the exchange step even in a world of one (rehearsal)
         self.rank, self.world = 0, 1
+        self.vgroup = None                          # vdb_shard_group handle (RCCL through the C ABI)
+        backend = None
         if group is not None or _dist_ready():
             import torch.distributed as dist
             self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+            backend = dist.get_backend(group)
+        fn = api.fn
+        if hasattr(fn, "shard_group_new") and fn.device_count() > 0 and (backend == "nccl" or (backend is None and always_exchange)):
+            self._make_group(backend)
+
+    def _make_group(self, backend):
+        """One RCCL communicator over the ranks of the process group, created by the library itself."""
+        import ctypes as C
+        import torch
+        dev = self._torch_device()
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            buf = (C.c_uint8 * 128)()
+            self.api.check(self.api.fn.shard_group_unique_id(C.cast(buf, C.c_void_p), 128))
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        if backend is not None and self.world > 1:
+            import torch.distributed as dist
+            t = ident.to(dev)                        # the process group is RCCL: its tensors live on the GPU
+            dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            ident = t.cpu()
+        raw = bytes(ident.tolist())
+        h = C.c_void_p()
+        self.api.check(self.api.fn.shard_group_new(raw, 128, self.rank, self.world, dev.index or 0, C.byref(h)))
+        self.vgroup = h.value
+
+    def __del__(self):
+        if getattr(self, "vgroup", None):
+            self.api.fn.shard_group_free(self.vgroup); self.vgroup = None
+
+    def rccl_ranks(self):
+        """Size of the library's communicator as RCCL reports it (0: no communicator)."""
+        return self.api.fn.shard_group_size(self.vgroup) if self.vgroup else 0
+
+    def search_batch_dev(self, d_q, nq, k, ef_search=0, stream=None):
+        """vdb_shard_search_batch_dev: the shard's search, all-gather and merge on one stream; device tensors in and out."""
+        return self._dev_call(lambda o, n, s: self.api.fn.shard_search_batch_dev(self.vgroup, self.index._h, d_q.data_ptr(), nq, k, ef_search, o, n, s), d_q, nq, k, stream)
+
+    def exact_knn_batch_dev(self, d_q, nq, k, stream=None):
+        return self._dev_call(lambda o, n, s: self.api.fn.shard_exact_knn_batch_dev(self.vgroup, self.index._h, d_q.data_ptr(), nq, k, o, n, s), d_q, nq, k, stream)
+
+    def segment_search_batch_dev(self, segment, d_q, nq, k, ef_search=0, filter=None, stream=None):
+        """Segment::search / search_with_filter over every rank's segment (each owns its slice of payloads and tombstones)."""
+        return self._dev_call(lambda o, n, s: self.api.fn.shard_segment_search_batch_dev(self.vgroup, segment._h, d_q.data_ptr(), nq, k, ef_search,
+                                                                                         filter._h if filter else None, o, n, s), d_q, nq, k, stream)
+
+    def _dev_call(self, call, d_q, nq, k, stream):
+        import torch
+        if not self.vgroup:
+            raise RuntimeError("no vdb_shard_group: the device-buffer sharded calls need the RCCL process group (or always_exchange)")
+        out = torch.zeros(nq * k * 16, dtype=torch.uint8, device=d_q.device); cnt = torch.zeros(nq, dtype=torch.int32, device=d_q.device)
+        own = stream is None
+        if own:                                      # a stream of this object's own: the null stream does not order against the library's
+            if not hasattr(self, "_stream"): self._stream = torch.cuda.Stream(device=d_q.device)
+            self._stream.wait_stream(torch.cuda.current_stream(d_q.device))
+            stream = self._stream.cuda_stream
+        self.api.check(call(out.data_ptr(), cnt.data_ptr(), stream))
+        if own: torch.cuda.current_stream(d_q.device).wait_stream(self._stream)
+        return out, cnt
 
     # ---- host-buffer path -------------------------------------------------------------------------
     def search_batch(self, queries, top_k, ef_search=0):
@@ -90,6 +154,12 @@ class ShardedIndex:
         import torch
         if self.world == 1 and not gathered and not self.always_exchange:
             return d_out, d_cnt
+        if not gathered and self.vgroup:            # RCCL all-gather + merge kernel inside the library, on torch's current stream
+            m_out = torch.empty(nq * k * 16, dtype=torch.uint8, device=d_out.device)
+            m_cnt = torch.empty(nq, dtype=torch.int32, device=d_out.device)
+            cur = torch.cuda.current_stream(d_out.device).cuda_stream
+            self.api.check(self.api.fn.shard_exchange_dev(self.vgroup, d_out.data_ptr(), d_cnt.data_ptr(), nq, k, m_out.data_ptr(), m_cnt.data_ptr(), cur))
+            return m_out, m_cnt
         if not gathered:
             import torch.distributed as dist
             if dist.get_backend(self.group) == "nccl":
