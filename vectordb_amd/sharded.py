@@ -63,15 +63,20 @@ class ShardedIndex:
         import torch
         dev = self._torch_device()
         ident = torch.zeros(128, dtype=torch.uint8)
-        if self.rank == 0:
+        import os
+        if self.rank == 0 and os.environ.get("VDB_SHARD_EXCHANGE", "") != "torch":
+            # an id of zeros tells every rank to stay with the process group's own all-gather (VDB_SHARD_EXCHANGE=torch,
+            # or a library without a usable RCCL): the decision is rank 0's, so no rank waits for a communicator alone
             buf = (C.c_uint8 * 128)()
-            self.api.check(self.api.fn.shard_group_unique_id(C.cast(buf, C.c_void_p), 128))
-            ident = torch.tensor(list(buf), dtype=torch.uint8)
+            if self.api.fn.shard_group_unique_id(C.cast(buf, C.c_void_p), 128) == 0:
+                ident = torch.tensor(list(buf), dtype=torch.uint8)
         if backend is not None and self.world > 1:
             import torch.distributed as dist
             t = ident.to(dev)                        # the process group is RCCL: its tensors live on the GPU
             dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
             ident = t.cpu()
+        if not bool(ident.any()):
+            return
         raw = bytes(ident.tolist())
         h = C.c_void_p()
         self.api.check(self.api.fn.shard_group_new(raw, 128, self.rank, self.world, dev.index or 0, C.byref(h)))
