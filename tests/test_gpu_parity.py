@@ -398,6 +398,33 @@ def test_a_small_visited_table_changes_the_work_not_the_results(ora, vdb, monkey
     assert _recall(got, gotn, exact, exact_n, k) >= _recall(ref, refn, exact, exact_n, k) - 0.005
 
 
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("dim", [128, 768])
+def test_exact_knn_with_a_large_shared_component_matches_brute_force(ora, vdb, monkeypatch, metric, dim):
+    """Cosine / dot rows with one large common component (all-positive embeddings, small angular spread): neighbours
+    differ by less than the candidate pass's bf16-split error, which no centring removes for these metrics.  The
+    re-rank compares the strict k-th key with the bounds the candidate pass dropped rows at and, where a dropped row
+    cannot be excluded, scores every row for that query: the oracle's brute force bit for bit.  Without that check
+    (VDB_KNN_NO_VERIFY=1) this data loses neighbours — the case is meant to need it."""
+    n, nq, k = (30000, 200, 10) if dim <= 256 else (9000, 100, 10)
+    rng = np.random.default_rng(700 + dim + metric)
+    xs = (100.0 + rng.standard_normal((n, dim)) * 0.05).astype(np.float32)
+    q = (100.0 + rng.standard_normal((nq, dim)) * 0.05).astype(np.float32)
+    xs = xs / np.linalg.norm(xs, axis=1, keepdims=True).astype(np.float32)     # unit rows for both metrics (embedding-like)
+    ids = np.arange(n, dtype=np.uint64) * 2 + 5
+    g = dict(ids=ids, levels=np.zeros(n, np.uint32), vectors=xs, deleted=np.zeros(n, np.uint8), layers=[], entry=int(ids[0]), current_max_level=0)
+    ho = ora.HNSWIndex(metric, 16, 64, 16, dim); ho.import_graph(g)
+    ref, refn = ho.exact_knn_batch(q, k)
+    hp = vdb.HNSWIndex(metric, 16, 64, 16, dim, arith=vdb.Arith.Fast); hp.import_graph(g)
+    got, gotn = hp.exact_knn_batch(q, k)
+    assert np.array_equal(refn, gotn)
+    assert np.array_equal(ref["id"], got["id"]), np.argwhere(ref["id"] != got["id"])[:5]
+    assert np.array_equal(ref["sort_key"].view(np.uint32), got["sort_key"].view(np.uint32))
+    monkeypatch.setenv("VDB_KNN_NO_VERIFY", "1")
+    raw, _ = hp.exact_knn_batch(q, k)
+    assert not np.array_equal(ref["id"], raw["id"]), "the unverified candidate pass was expected to lose neighbours here"
+
+
 def test_exact_knn_ties_break_by_id(ora, vdb):
     d = 8
     base = np.zeros((40, d), np.float32); base[:, 0] = np.repeat(np.arange(10), 4)     # 4-way exact ties

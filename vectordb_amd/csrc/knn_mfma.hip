@@ -152,7 +152,8 @@ __global__ void __launch_bounds__(256) knn_centre_kernel(GraphView gv, float* __
     centre[d] = s;
 }
 
-__global__ void __launch_bounds__(256) knn_prepare_kernel(GraphView gv, const float* __restrict__ centre, float* __restrict__ scale, float* __restrict__ bias) {
+__global__ void __launch_bounds__(256) knn_prepare_kernel(GraphView gv, const float* __restrict__ centre, float* __restrict__ scale, float* __restrict__ bias,
+                                                         uint32_t* __restrict__ max_norm2) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t r = t >> 3, part = t & 7;                   // eight lanes share a row, 16 bytes each per step
     const bool in = r < gv.n;
@@ -165,12 +166,21 @@ __global__ void __launch_bounds__(256) knn_prepare_kernel(GraphView gv, const fl
         s = __builtin_fmaf(v.x, v.x, s); s = __builtin_fmaf(v.y, v.y, s); s = __builtin_fmaf(v.z, v.z, s); s = __builtin_fmaf(v.w, v.w, s);
     }
     s = group_sum<8>(s);
+    const bool dead = !in || (gv.deleted && bit_test(gv.deleted, slot));
+    // largest squared norm of the block's live rows, one atomic per block (s >= 0: its bit pattern orders like the value)
+    __shared__ uint32_t wmax[4];
+    uint32_t mx = dead ? 0u : __float_as_uint(s);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(max_norm2, max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
     if (!in || part != 0) return;
     float sc, bi = 0.f;
     if (gv.metric == VDB_EUCLIDEAN) { sc = -2.f; bi = s; }
     else if (gv.metric == VDB_DOT) sc = -1.f;
     else sc = s > 0.f ? -1.0f / __builtin_sqrtf(s) : 0.f;
-    if (gv.deleted && bit_test(gv.deleted, slot)) { sc = 0.f; bi = INF_F; }
+    if (dead) { sc = 0.f; bi = INF_F; }
     scale[r] = sc; bias[r] = bi;
 }
 
@@ -179,7 +189,7 @@ __global__ void __launch_bounds__(256) knn_prepare_kernel(GraphView gv, const fl
 template <int KH, int KNN_KP>
 __global__ void __launch_bounds__(256) knn_mfma_kernel(GraphView gv, const float* __restrict__ queries, uint32_t nq,
                                                       const float* __restrict__ scale, const float* __restrict__ bias,
-                                                      uint32_t* __restrict__ out_slots, uint32_t n_chunks) {
+                                                      uint32_t* __restrict__ out_slots, float* __restrict__ out_thr, uint32_t n_chunks) {
     constexpr int K = 2 * KH, LDA = K + 4;                     // padded tile row: conflict-free 16-byte reads
     constexpr int KNN_CAP = KnnBuf<KNN_KP>::CAP;
     // 32-row tiles written to LDS per pair of block barriers.  Two (64-row steps, half the barriers) measured the same
@@ -278,8 +288,12 @@ __global__ void __launch_bounds__(256) knn_mfma_kernel(GraphView gv, const float
     for (int jj = 0; jj < 32; ++jj) {
         const uint32_t qi = wave * 32 + jj, qg = blockIdx.y * MQ + qi;
         if (qg >= nq) break;
-        if (cnt[qi] > KNN_KP) { float nt; uint32_t ni; knn_compact<KNN_KP, KNN_CAP>(gv, cnt, buf, qi, nt, ni); }
+        // the bound every row this chunk dropped for the query was at or above: the KP-th key held at the end, +inf if
+        // fewer than KP rows were ever held (then nothing was dropped)
+        float fin = readlane_f(thr, jj);
+        if (cnt[qi] > KNN_KP) { uint32_t ni; knn_compact<KNN_KP, KNN_CAP>(gv, cnt, buf, qi, fin, ni); }
         const uint32_t n = cnt[qi];
+        if (lane == 0) out_thr[(size_t)qg * n_chunks + blockIdx.x] = fin;
         if (lane < KNN_KP) out_slots[((size_t)qg * n_chunks + blockIdx.x) * KNN_KP + lane] = (uint32_t)lane < n ? buf[qi * KNN_CAP + lane].y : NONE32;
     }
 }
@@ -322,7 +336,7 @@ __global__ void __launch_bounds__(256) knn_split_queries_kernel(const float* __r
 template <int KS, int KNN_KP, int WPB>
 __global__ void __launch_bounds__(64 * WPB) knn_bf16_kernel(GraphView gv, const __bf16* __restrict__ qh, const __bf16* __restrict__ ql, uint32_t nq,
                                                       const float* __restrict__ centre, const float* __restrict__ scale, const float* __restrict__ bias,
-                                                      uint32_t* __restrict__ out_slots, uint32_t n_chunks) {
+                                                      uint32_t* __restrict__ out_slots, float* __restrict__ out_thr, uint32_t n_chunks) {
     constexpr int K = 16 * KS, LDB = K + 8;                    // bf16 per tile row, padded by 16 bytes: conflict-free 16-byte reads
     constexpr int KNN_CAP = KnnBuf<KNN_KP>::CAP;
     constexpr int MQB = 32 * WPB;                              // queries per block: 32 per wave
@@ -439,8 +453,12 @@ __global__ void __launch_bounds__(64 * WPB) knn_bf16_kernel(GraphView gv, const 
     for (int jj = 0; jj < 32; ++jj) {
         const uint32_t qi = wave * 32 + jj, qg = blockIdx.y * MQB + qi;
         if (qg >= nq) break;
-        if (cnt[qi] > KNN_KP) { float nt; uint32_t ni; knn_compact<KNN_KP, KNN_CAP>(gv, cnt, buf, qi, nt, ni); }
+        // the bound every row this chunk dropped for the query was at or above: the KP-th key held at the end, +inf if
+        // fewer than KP rows were ever held (then nothing was dropped)
+        float fin = readlane_f(thr, jj);
+        if (cnt[qi] > KNN_KP) { uint32_t ni; knn_compact<KNN_KP, KNN_CAP>(gv, cnt, buf, qi, fin, ni); }
         const uint32_t n = cnt[qi];
+        if (lane == 0) out_thr[(size_t)qg * n_chunks + blockIdx.x] = fin;
         if (lane < KNN_KP) out_slots[((size_t)qg * n_chunks + blockIdx.x) * KNN_KP + lane] = (uint32_t)lane < n ? buf[qi * KNN_CAP + lane].y : NONE32;
     }
 }
@@ -455,7 +473,7 @@ constexpr int LT = 128, KC = 32, LDK = KC + 4;
 template <int KNN_KP>
 __global__ void __launch_bounds__(256) knn_mfma_long_kernel(GraphView gv, const float* __restrict__ queries, uint32_t nq,
                                                            const float* __restrict__ scale, const float* __restrict__ bias,
-                                                           uint32_t* __restrict__ out_slots, uint32_t n_chunks) {
+                                                           uint32_t* __restrict__ out_slots, float* __restrict__ out_thr, uint32_t n_chunks) {
     constexpr int KNN_CAP = KnnBuf<KNN_KP>::CAP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* At = reinterpret_cast<float*>(smem);                                  // 2 x LT x LDK
@@ -558,8 +576,12 @@ __global__ void __launch_bounds__(256) knn_mfma_long_kernel(GraphView gv, const 
     for (int jj = 0; jj < 32; ++jj) {
         const uint32_t qi = wave * 32 + jj, qg = blockIdx.y * MQ + qi;
         if (qg >= nq) break;
-        if (cnt[qi] > KNN_KP) { float nt; uint32_t ni; knn_compact<KNN_KP, KNN_CAP>(gv, cnt, buf, qi, nt, ni); }
+        // the bound every row this chunk dropped for the query was at or above: the KP-th key held at the end, +inf if
+        // fewer than KP rows were ever held (then nothing was dropped)
+        float fin = readlane_f(thr, jj);
+        if (cnt[qi] > KNN_KP) { uint32_t ni; knn_compact<KNN_KP, KNN_CAP>(gv, cnt, buf, qi, fin, ni); }
         const uint32_t n = cnt[qi];
+        if (lane == 0) out_thr[(size_t)qg * n_chunks + blockIdx.x] = fin;
         if (lane < KNN_KP) out_slots[((size_t)qg * n_chunks + blockIdx.x) * KNN_KP + lane] = (uint32_t)lane < n ? buf[qi * KNN_CAP + lane].y : NONE32;
     }
 }
@@ -575,7 +597,7 @@ constexpr int KC2 = 32, LDK2 = KC2 + 8;
 template <int KNN_KP>
 __global__ void __launch_bounds__(256, 2) knn_bf16_long_kernel(GraphView gv, const __bf16* __restrict__ qh, const __bf16* __restrict__ ql, uint32_t kq, uint32_t nq,
                                                            const float* __restrict__ centre, const float* __restrict__ scale, const float* __restrict__ bias,
-                                                           uint32_t* __restrict__ out_slots, uint32_t n_chunks) {
+                                                           uint32_t* __restrict__ out_slots, float* __restrict__ out_thr, uint32_t n_chunks) {
     constexpr int KNN_CAP = KnnBuf<KNN_KP>::CAP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __bf16* Ah = reinterpret_cast<__bf16*>(smem);                                // LT x LDK2 high parts
@@ -691,8 +713,12 @@ __global__ void __launch_bounds__(256, 2) knn_bf16_long_kernel(GraphView gv, con
     for (int jj = 0; jj < 32; ++jj) {
         const uint32_t qi = wave * 32 + jj, qg = blockIdx.y * MQ + qi;
         if (qg >= nq) break;
-        if (cnt[qi] > KNN_KP) { float nt; uint32_t ni; knn_compact<KNN_KP, KNN_CAP>(gv, cnt, buf, qi, nt, ni); }
+        // the bound every row this chunk dropped for the query was at or above: the KP-th key held at the end, +inf if
+        // fewer than KP rows were ever held (then nothing was dropped)
+        float fin = readlane_f(thr, jj);
+        if (cnt[qi] > KNN_KP) { uint32_t ni; knn_compact<KNN_KP, KNN_CAP>(gv, cnt, buf, qi, fin, ni); }
         const uint32_t n = cnt[qi];
+        if (lane == 0) out_thr[(size_t)qg * n_chunks + blockIdx.x] = fin;
         if (lane < KNN_KP) out_slots[((size_t)qg * n_chunks + blockIdx.x) * KNN_KP + lane] = (uint32_t)lane < n ? buf[qi * KNN_CAP + lane].y : NONE32;
     }
 }
@@ -728,8 +754,18 @@ struct TopKList {
     }
 };
 
+// The candidate pass ranks rows by approximate keys; a row it dropped for (query, chunk) had an approximate key at or
+// above that chunk's final bound thr.  With err = the most an approximate key and a strict key can differ (both against
+// the real value: the bf16 split leaves at most 2^-14 of sum |q_i x_i| <= |q||x|, the strict fp32 sum dim * 2^-24 of it; the
+// budget used is 2^-13 + dim * 2^-23), a dropped row can precede the strict k-th result only if thr - err <= k-th key.
+// Where that cannot be excluded the query is flagged and knn_fallback_kernel scores every row for it.
+//   dot:     approximate key = -q.x = sort key;                         err = E |q| max|x|
+//   cosine:  approximate key = -q.x / |x|, sort key = 1 + that / |q|;    err = E (relative to 1)
+//   L2:      approximate key = |x-c|^2 - 2 (q-c).(x-c) = dist^2 - |q-c|^2; err = E (|q-c| + max|x-c|)^2, compared in dist^2
 __global__ void __launch_bounds__(64) knn_rerank_kernel(GraphView gv, const float* __restrict__ queries, uint32_t top_k,
                                                        const uint32_t* __restrict__ slots, uint32_t per_query,
+                                                       const float* __restrict__ thr, uint32_t n_chunks, const float* __restrict__ centre,
+                                                       const uint32_t* __restrict__ max_norm2, uint32_t* __restrict__ flags, uint32_t* __restrict__ flag_count,
                                                        vdb_scored_point* __restrict__ out, uint32_t* __restrict__ out_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = lane_id();
@@ -740,6 +776,9 @@ __global__ void __launch_bounds__(64) knn_rerank_kernel(GraphView gv, const floa
     float* lraw = lkey + top_k;
     for (uint32_t i = lane; i < stride; i += WAVE) ql[i] = i < dim ? queries[(size_t)q * dim + i] : 0.f;
     wave_sync();
+    float qn2 = 0.f;                                                          // |q - c|^2 (c = 0 unless Euclidean), for the verification below
+    for (uint32_t i = lane; i < dim; i += WAVE) { const float d = ql[i] - (centre ? centre[i] : 0.f); qn2 = __builtin_fmaf(d, d, qn2); }
+    qn2 = group_sum<64>(qn2);
     if (gv.metric == VDB_COSINE) {                                            // hnsw.rs:526-536, 752-764
         float s = -0.0f;
         for (uint32_t i = 0; i < dim; ++i) { float p = ql[i] * ql[i]; s = s + p; }
@@ -768,6 +807,87 @@ __global__ void __launch_bounds__(64) knn_rerank_kernel(GraphView gv, const floa
     }
     for (uint32_t i = lane; i < L.n; i += WAVE) { vdb_scored_point sp; sp.id = lid[i]; sp.raw_score = lraw[i]; sp.sort_key = lkey[i]; out[(size_t)q * top_k + i] = sp; }
     if (lane == 0) out_n[q] = L.n;
+    if (flags) {
+        // smallest bound over the chunks (chunks that dropped nothing report +inf)
+        float lo = INF_F;
+        for (uint32_t c = lane; c < n_chunks; c += WAVE) lo = __builtin_fminf(lo, thr[(size_t)q * n_chunks + c]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) lo = __builtin_fminf(lo, __shfl_xor(lo, off));
+        bool unsure = false;
+        if (lo < INF_F) {
+            if (L.n < top_k) unsure = true;                                   // rows were dropped although the list is not full
+            else {
+                const float kth = lkey[top_k - 1];
+                const float E = 1.220703125e-4f + (float)dim * 1.1920929e-7f;
+                const float xm = __builtin_sqrtf(__uint_as_float(*max_norm2)), qn = __builtin_sqrtf(qn2);
+                if (gv.metric == VDB_DOT) unsure = !(lo - E * qn * xm > kth);
+                else if (gv.metric == VDB_COSINE) unsure = !(qn > 0.f && 1.0f + lo / qn - E > kth);
+                else unsure = !(lo + qn2 - E * (qn + xm) * (qn + xm) > kth * kth * (1.0f + 2.4e-7f));
+            }
+        }
+        if (lane == 0 && unsure) flags[atomicAdd(flag_count, 1u)] = q;          // the list of queries to score in full
+    }
+}
+
+// Every live row scored in strict arithmetic for the queries the verification listed (a block of 16 wavefronts takes
+// one listed query at a time): each wavefront keeps the top_k of its share of the rows, wavefront 0 merges them by
+// (sort_key, id).  Replaces the query's results.
+constexpr int FB_WAVES = 16;
+__global__ void __launch_bounds__(64 * FB_WAVES) knn_fallback_kernel(GraphView gv, const float* __restrict__ queries, uint32_t top_k,
+                                                                   const uint32_t* __restrict__ flags, const uint32_t* __restrict__ flag_count,
+                                                                   vdb_scored_point* __restrict__ out, uint32_t* __restrict__ out_n) {
+    const uint32_t listed = *flag_count;
+    for (uint32_t fi = blockIdx.x; fi < listed; fi += gridDim.x) {
+    const uint32_t q = flags[fi];
+    __syncthreads();                                                          // the previous query's lists are done with
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t dim = gv.dim, stride = gv.stride;
+    float* ql = reinterpret_cast<float*>(smem);
+    uint64_t* lid = reinterpret_cast<uint64_t*>(smem + (size_t)stride * 4) + (size_t)wave * top_k;
+    float* lkey = reinterpret_cast<float*>(smem + (size_t)stride * 4 + (size_t)FB_WAVES * top_k * 8) + (size_t)wave * top_k;
+    float* lraw = lkey + (size_t)FB_WAVES * top_k;
+    uint32_t* ln = reinterpret_cast<uint32_t*>(smem + (size_t)stride * 4 + (size_t)FB_WAVES * top_k * 16);
+    for (uint32_t i = threadIdx.x; i < stride; i += blockDim.x) ql[i] = i < dim ? queries[(size_t)q * dim + i] : 0.f;
+    __syncthreads();
+    if (gv.metric == VDB_COSINE) {                                            // hnsw.rs:526-536, 752-764
+        float s = -0.0f;
+        for (uint32_t i = 0; i < dim; ++i) { float p = ql[i] * ql[i]; s = s + p; }
+        const float norm = __builtin_sqrtf(s);
+        __syncthreads();
+        if (norm != 0.0f) for (uint32_t i = threadIdx.x; i < dim; i += blockDim.x) ql[i] = ql[i] / norm;
+        __syncthreads();
+    }
+    TopKList L{lkey, lid, lraw, 0, top_k};
+    for (uint32_t b = wave * WAVE; b < gv.n; b += FB_WAVES * WAVE) {
+        const uint32_t pos = b + lane;
+        uint32_t s = pos < gv.n ? (gv.rowmap ? gv.rowmap[pos] : pos) : 0u;
+        const bool valid = pos < gv.n && !(gv.deleted && bit_test(gv.deleted, s));
+        float raw = 0.f; uint64_t idv = 0;
+        if (valid) { raw = strict_pair(ql, gv.vecs + (size_t)s * stride, dim, gv.metric, true); idv = gv.ids[s]; }
+        const float k = gv.metric == VDB_DOT ? -raw : raw;
+        uint64_t am = ballot(valid && L.admits(k, idv));
+        while (am) {
+            const int jj = __ffsll((unsigned long long)am) - 1; am &= am - 1;
+            const float kk = readlane_f(k, jj), rr = readlane_f(raw, jj);
+            const uint64_t ii = ((uint64_t)readlane_u((uint32_t)(idv >> 32), jj) << 32) | readlane_u((uint32_t)idv, jj);
+            if (!L.admits(kk, ii)) continue;
+            L.insert(kk, ii, rr);
+        }
+    }
+    if (lane == 0) ln[wave] = L.n;
+    __syncthreads();
+    if (wave != 0) continue;
+    for (int w = 1; w < FB_WAVES; ++w) {                                       // wavefront 0 takes in the other lists
+        const uint32_t nw = ln[w];
+        for (uint32_t i = 0; i < nw; ++i) {
+            const float kk = lkey[(size_t)w * top_k + i]; const uint64_t ii = lid[(size_t)w * top_k + i]; const float rr = lraw[(size_t)w * top_k + i];
+            if (L.admits(kk, ii)) L.insert(kk, ii, rr);
+        }
+    }
+    for (uint32_t i = lane; i < L.n; i += WAVE) { vdb_scored_point sp; sp.id = lid[i]; sp.raw_score = lraw[i]; sp.sort_key = lkey[i]; out[(size_t)q * top_k + i] = sp; }
+    if (lane == 0) out_n[q] = L.n;
+    }
 }
 
 // Blocks of one launch do equal work, so the launch lasts ceil(blocks / resident blocks) rounds: the base set is cut
@@ -792,18 +912,18 @@ uint32_t resident_blocks(Kernel kernel, size_t lds) {
     return (uint32_t)std::max(1, cus) * (uint32_t)std::max(1, per_cu);
 }
 template <int KH, int KP>
-uint32_t launch_mfma(const GraphView& g, const float* queries, uint32_t nq, const float* scale, const float* bias, uint32_t* slots, uint32_t max_chunks, hipStream_t st) {
+uint32_t launch_mfma(const GraphView& g, const float* queries, uint32_t nq, const float* scale, const float* bias, uint32_t* slots, float* thr, uint32_t max_chunks, hipStream_t st) {
     constexpr int K = 2 * KH;
     constexpr int ROWS = MT;
     const size_t lds = ((size_t)ROWS * (K + 4) * 4 + 2 * ROWS * 4) + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8;
     const uint32_t n_chunks = pick_chunks(g.n, nq, MQ, resident_blocks(knn_mfma_kernel<KH, KP>, lds), max_chunks);
-    hipLaunchKernelGGL((knn_mfma_kernel<KH, KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, queries, nq, scale, bias, slots, n_chunks);
+    hipLaunchKernelGGL((knn_mfma_kernel<KH, KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, queries, nq, scale, bias, slots, thr, n_chunks);
     return n_chunks;
 }
 // padded row length of the bf16 planes of the queries
 inline uint32_t knn_bf16_k(uint32_t stride) { return stride <= 64 ? 64u : stride <= 128 ? 128u : stride <= 256 ? 256u : (stride + 63u) / 64u * 64u; }
 template <int KS, int KP, int WPB>
-uint32_t launch_bf16(const GraphView& g, const __bf16* qh, const __bf16* ql, uint32_t nq, const float* centre, const float* scale, const float* bias, uint32_t* slots, uint32_t max_chunks, hipStream_t st) {
+uint32_t launch_bf16(const GraphView& g, const __bf16* qh, const __bf16* ql, uint32_t nq, const float* centre, const float* scale, const float* bias, uint32_t* slots, float* thr, uint32_t max_chunks, hipStream_t st) {
     constexpr int K = 16 * KS, MQB = 32 * WPB;
     const size_t lds = (size_t)KNN_BF16_BUFFERS * ((size_t)2 * MT * (K + 8) * 2 + 2 * MT * 4) + MQB * 4 + (size_t)MQB * KnnBuf<KP>::CAP * 8;
     int dev = 0, cus = 256, per_cu = 1;
@@ -811,28 +931,28 @@ uint32_t launch_bf16(const GraphView& g, const __bf16* qh, const __bf16* ql, uin
     VDB_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     VDB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, knn_bf16_kernel<KS, KP, WPB>, 64 * WPB, lds));
     const uint32_t n_chunks = pick_chunks(g.n, nq, MQB, (uint32_t)std::max(1, cus) * (uint32_t)std::max(1, per_cu), max_chunks);
-    hipLaunchKernelGGL((knn_bf16_kernel<KS, KP, WPB>), dim3(n_chunks, (nq + MQB - 1) / MQB), dim3(64 * WPB), lds, st, g, qh, ql, nq, centre, scale, bias, slots, n_chunks);
+    hipLaunchKernelGGL((knn_bf16_kernel<KS, KP, WPB>), dim3(n_chunks, (nq + MQB - 1) / MQB), dim3(64 * WPB), lds, st, g, qh, ql, nq, centre, scale, bias, slots, thr, n_chunks);
     return n_chunks;
 }
 template <int KP>
-uint32_t launch_bf16_any(const GraphView& g, const __bf16* qh, const __bf16* ql, uint32_t nq, const float* centre, const float* scale, const float* bias, uint32_t* slots, uint32_t max_chunks, hipStream_t st) {
+uint32_t launch_bf16_any(const GraphView& g, const __bf16* qh, const __bf16* ql, uint32_t nq, const float* centre, const float* scale, const float* bias, uint32_t* slots, float* thr, uint32_t max_chunks, hipStream_t st) {
     const bool force_long = std::getenv("VDB_KNN_LONG") != nullptr;   // diagnostic: the chunked kernel on short rows
-    if (!force_long && g.stride <= 64) return launch_bf16<4, KP, 4>(g, qh, ql, nq, centre, scale, bias, slots, max_chunks, st);
-    if (!force_long && g.stride <= 128) return launch_bf16<8, KP, 4>(g, qh, ql, nq, centre, scale, bias, slots, max_chunks, st);
-    if (!force_long && g.stride <= 256) return launch_bf16<16, KP, 8>(g, qh, ql, nq, centre, scale, bias, slots, max_chunks, st);
+    if (!force_long && g.stride <= 64) return launch_bf16<4, KP, 4>(g, qh, ql, nq, centre, scale, bias, slots, thr, max_chunks, st);
+    if (!force_long && g.stride <= 128) return launch_bf16<8, KP, 4>(g, qh, ql, nq, centre, scale, bias, slots, thr, max_chunks, st);
+    if (!force_long && g.stride <= 256) return launch_bf16<16, KP, 8>(g, qh, ql, nq, centre, scale, bias, slots, thr, max_chunks, st);
     const size_t lds = (size_t)2 * LT * LDK2 * 2 + 2 * LT * 4 + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8 + (size_t)knn_bf16_k(g.stride) * 4;
     const uint32_t n_chunks = pick_chunks(g.n, nq, MQ, resident_blocks(knn_bf16_long_kernel<KP>, lds), max_chunks);
-    hipLaunchKernelGGL((knn_bf16_long_kernel<KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, qh, ql, knn_bf16_k(g.stride), nq, centre, scale, bias, slots, n_chunks);
+    hipLaunchKernelGGL((knn_bf16_long_kernel<KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, qh, ql, knn_bf16_k(g.stride), nq, centre, scale, bias, slots, thr, n_chunks);
     return n_chunks;
 }
 template <int KP>
-uint32_t launch_mfma_any(const GraphView& g, const float* queries, uint32_t nq, const float* scale, const float* bias, uint32_t* slots, uint32_t max_chunks, hipStream_t st) {
-    if (g.stride <= 64) return launch_mfma<32, KP>(g, queries, nq, scale, bias, slots, max_chunks, st);
-    if (g.stride <= 128) return launch_mfma<64, KP>(g, queries, nq, scale, bias, slots, max_chunks, st);
-    if (g.stride <= 256) return launch_mfma<128, KP>(g, queries, nq, scale, bias, slots, max_chunks, st);
+uint32_t launch_mfma_any(const GraphView& g, const float* queries, uint32_t nq, const float* scale, const float* bias, uint32_t* slots, float* thr, uint32_t max_chunks, hipStream_t st) {
+    if (g.stride <= 64) return launch_mfma<32, KP>(g, queries, nq, scale, bias, slots, thr, max_chunks, st);
+    if (g.stride <= 128) return launch_mfma<64, KP>(g, queries, nq, scale, bias, slots, thr, max_chunks, st);
+    if (g.stride <= 256) return launch_mfma<128, KP>(g, queries, nq, scale, bias, slots, thr, max_chunks, st);
     const size_t lds = (size_t)2 * LT * LDK * 4 + 2 * LT * 4 + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8;
     const uint32_t n_chunks = pick_chunks(g.n, nq, MQ, resident_blocks(knn_mfma_long_kernel<KP>, lds), max_chunks);
-    hipLaunchKernelGGL((knn_mfma_long_kernel<KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, queries, nq, scale, bias, slots, n_chunks);
+    hipLaunchKernelGGL((knn_mfma_long_kernel<KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, queries, nq, scale, bias, slots, thr, n_chunks);
     return n_chunks;
 }
 inline uint32_t knn_kp(uint32_t top_k) { return top_k + 4 <= 16 ? 16u : 32u; }
@@ -842,12 +962,16 @@ inline uint32_t knn_kp(uint32_t top_k) { return top_k + 4 <= 16 ? 16u : 32u; }
 bool knn_mfma_supported(const GraphView& g, uint32_t top_k) { return top_k >= 1 && top_k + 4 <= 32 && g.stride <= MAX_DIM && g.n > 0; }
 // room for the largest chunk count and candidate width the launch may pick
 // words of the fixed part of the scratch: the centre, row scale and bias (rounded up to 16 bytes) and the two bf16 planes of the queries
-static size_t knn_fixed_words(uint32_t n, uint32_t nq, uint32_t stride) { return knn_bf16_k(stride) + ((2 * (size_t)n + 3) & ~size_t(3)) + (size_t)nq * knn_bf16_k(stride); }
+// (and, for the verification of the candidate pass, the largest squared row norm — four words — and one flag per query)
+static size_t knn_fixed_words(uint32_t n, uint32_t nq, uint32_t stride) {
+    return knn_bf16_k(stride) + ((2 * (size_t)n + 3) & ~size_t(3)) + (size_t)nq * knn_bf16_k(stride) + 4 + (((size_t)nq + 3) & ~size_t(3));
+}
 size_t knn_mfma_scratch_words(uint32_t n, uint32_t nq, uint32_t stride) {
-    return knn_fixed_words(n, nq, stride) + (size_t)nq * std::max<uint32_t>(1, std::min<uint32_t>(64, n / 4096)) * 32;
+    return knn_fixed_words(n, nq, stride) + (size_t)nq * std::max<uint32_t>(1, std::min<uint32_t>(64, n / 4096)) * 33;
 }
 
-// scratch: [centre K][scale n][bias n][query planes: 2 x nq x K bf16][candidate slots: nq x chunks x KP], chunks <= max_chunks
+// scratch: [centre K][scale n][bias n][query planes: 2 x nq x K bf16][largest squared row norm: 4][flags nq]
+//          [candidate slots: nq x max_chunks x KP][final bounds: nq x max_chunks]
 static void run_exact_knn_mfma(const GraphView& g, const float* queries, uint32_t nq, uint32_t top_k, vdb_scored_point* out, uint32_t* out_n,
                                uint32_t* scratch, uint32_t max_chunks, hipStream_t st) {
     const uint32_t kpad = knn_bf16_k(g.stride);
@@ -855,13 +979,19 @@ static void run_exact_knn_mfma(const GraphView& g, const float* queries, uint32_
     float* centre = reinterpret_cast<float*>(scratch);
     float* scale = centre + kpad; float* bias = scale + g.n;
     __bf16* qh = reinterpret_cast<__bf16*>(scratch + kpad + ((2 * (size_t)g.n + 3) & ~size_t(3))); __bf16* ql = qh + (size_t)nq * kpad;
+    uint32_t* max_norm2 = scratch + kpad + ((2 * (size_t)g.n + 3) & ~size_t(3)) + (size_t)nq * kpad;
+    uint32_t* flags = max_norm2 + 4;
     uint32_t* slots = scratch + knn_fixed_words(g.n, nq, g.stride);
+    // the launch takes at most this many chunks (pick_chunks), and the scratch is sized for them
+    const uint32_t cap_chunks = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(64, max_chunks), g.n / 4096));
+    float* thr = reinterpret_cast<float*>(slots + (size_t)nq * cap_chunks * knn_kp(top_k));
+    VDB_HIP(hipMemsetAsync(max_norm2, 0, 16, st));
     if (bf16) {
         hipLaunchKernelGGL(knn_centre_kernel, dim3((kpad + 255) / 256), dim3(256), 0, st, g, centre, kpad,
                            std::getenv("VDB_KNN_NO_CENTRE") ? 0u : std::min<uint32_t>(g.n, 2048u));   // (diagnostic: what the centring buys)
         VDB_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(knn_prepare_kernel, dim3((g.n + 31) / 32), dim3(256), 0, st, g, bf16 ? centre : nullptr, scale, bias);
+    hipLaunchKernelGGL(knn_prepare_kernel, dim3((g.n + 31) / 32), dim3(256), 0, st, g, bf16 ? centre : nullptr, scale, bias, max_norm2);
     VDB_HIP(hipGetLastError());
     const uint32_t kp = knn_kp(top_k);
     uint32_t n_chunks;
@@ -869,16 +999,24 @@ static void run_exact_knn_mfma(const GraphView& g, const float* queries, uint32_
         const size_t cells = (size_t)nq * kpad;
         hipLaunchKernelGGL(knn_split_queries_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, queries, centre, nq, g.dim, kpad, qh, ql);
         VDB_HIP(hipGetLastError());
-        n_chunks = kp == 16 ? launch_bf16_any<16>(g, qh, ql, nq, centre, scale, bias, slots, max_chunks, st)
-                            : launch_bf16_any<32>(g, qh, ql, nq, centre, scale, bias, slots, max_chunks, st);
+        n_chunks = kp == 16 ? launch_bf16_any<16>(g, qh, ql, nq, centre, scale, bias, slots, thr, max_chunks, st)
+                            : launch_bf16_any<32>(g, qh, ql, nq, centre, scale, bias, slots, thr, max_chunks, st);
     } else {
-        n_chunks = kp == 16 ? launch_mfma_any<16>(g, queries, nq, scale, bias, slots, max_chunks, st)
-                            : launch_mfma_any<32>(g, queries, nq, scale, bias, slots, max_chunks, st);
+        n_chunks = kp == 16 ? launch_mfma_any<16>(g, queries, nq, scale, bias, slots, thr, max_chunks, st)
+                            : launch_mfma_any<32>(g, queries, nq, scale, bias, slots, thr, max_chunks, st);
     }
     VDB_HIP(hipGetLastError());
     const size_t lds = (size_t)g.stride * 4 + (size_t)top_k * 16;
-    hipLaunchKernelGGL(knn_rerank_kernel, dim3(nq), dim3(64), lds, st, g, queries, top_k, slots, n_chunks * kp, out, out_n);
+    // (the fp32 MFMA pass, kept as a diagnostic, is not verified: its keys carry a different error)
+    const bool verify = bf16 && !std::getenv("VDB_KNN_NO_VERIFY");
+    hipLaunchKernelGGL(knn_rerank_kernel, dim3(nq), dim3(64), lds, st, g, queries, top_k, slots, n_chunks * kp, thr, n_chunks,
+                       g.metric == VDB_EUCLIDEAN ? centre : nullptr, max_norm2, verify ? flags : nullptr, max_norm2 + 1, out, out_n);
     VDB_HIP(hipGetLastError());
+    if (verify) {
+        const size_t fl = (size_t)g.stride * 4 + (size_t)FB_WAVES * top_k * 16 + FB_WAVES * 4;
+        hipLaunchKernelGGL(knn_fallback_kernel, dim3(std::min<uint32_t>(nq, 1024u)), dim3(64 * FB_WAVES), fl, st, g, queries, top_k, flags, max_norm2 + 1, out, out_n);
+        VDB_HIP(hipGetLastError());
+    }
 }
 
 // scratch: knn_mfma_scratch_words() dwords
@@ -921,7 +1059,7 @@ void launch_exact_knn_mfma_static(const GraphView& g, const float* queries, uint
                                   hipStream_t st) {
     if (nq == 0) return;
     const uint32_t kp = knn_kp(top_k);
-    const size_t fixed = knn_fixed_words(g.n, nq, g.stride), per_chunk = (size_t)nq * kp;
+    const size_t fixed = knn_fixed_words(g.n, nq, g.stride), per_chunk = (size_t)nq * (kp + 1);
     if (fixed + per_chunk > KNN_STATIC_WORDS)
         throw Failure(err_arg("exact k-NN without allocation: 2 * rows + queries * (" + std::to_string(kp) + " + padded row length up to 256) = " + std::to_string(fixed + per_chunk) +
                               " words exceed the static scratch of " + std::to_string(KNN_STATIC_WORDS) + " words (16 MiB); use vdb_index_exact_knn_batch_dev"));
