@@ -225,10 +225,14 @@ vdb_status vdb_index_exact_knn_batch_dev(const vdb_index* x, const float* d_quer
 /* The same as vdb_index_exact_knn_batch_dev with NO allocation (no counterpart in the reference; for callers that
  * cannot allocate: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  The
  * candidate pass works in a 16 MiB scratch array that is part of the library's code object (one copy per GPU, held
- * until the process ends).  Limits: FAST index, 1 <= top_k <= 28, K + 2 * rows + nq * (K + (top_k <= 12 ? 16 : 32)) <= 4 Mi
- * words with K the padded row length (64, 128, 256, else the next multiple of 32), and no edit pending (after inserts or mark_deleted call vdb_index_sync_device first); anything else is
- * VDB_ERR_ARGUMENT and nothing is launched.  Every call on one GPU shares the scratch array: calls that overlap on
- * one GPU (any index, any stream) race, so order them on one stream or with events. */
+ * until the process ends).  Limits: FAST index, 1 <= top_k <= 28, nq < 2^32,
+ * K + 2 * rows + nq * (K + 2 + (top_k <= 12 ? 17 : 33)) + 8 <= 4 Mi words with K the padded row length (64, 128, 256, else the
+ * next multiple of 64), and no edit pending (after inserts or mark_deleted call vdb_index_sync_device first); anything
+ * else — an empty index and top_k = 0 included, which the allocating entry points answer with zero counts — is
+ * VDB_ERR_ARGUMENT and nothing is launched.  The call makes no allocation; it does query the device (current device,
+ * occupancy, the scratch symbol's address on first use), so under graph capture make one call before the capture begins.
+ * Every call on one GPU shares the scratch array: calls that overlap on one GPU (any index, any stream) race, so order
+ * them on one stream or with events. */
 vdb_status vdb_index_exact_knn_batch_dev_noalloc(const vdb_index* x, const float* d_queries, size_t nq, size_t top_k,
                                                  vdb_scored_point* d_out, uint32_t* d_out_n, void* stream);
 

@@ -753,6 +753,7 @@ void vdb_index::exact_knn(const float* q, size_t nq, size_t top_k, bool dev, vdb
 
 void vdb_index::exact_knn_static(const float* d_q, size_t nq, size_t top_k, vdb_scored_point* d_out, uint32_t* d_out_n, hipStream_t s) {
     if (nq == 0) return;
+    if (nq > 0xFFFFFFFFull) throw Failure(err_arg("exact k-NN without allocation: more than 2^32 - 1 queries in one call"));
     std::lock_guard<std::mutex> lk(mu);
     use_device();
     if (!s) s = stream;
