@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, datasheet
-KERNEL_SOURCES = ("search_kernel.hpp", "device_common.hpp", "kernels.hpp", "common.hpp", "search_plain.hip")
+KERNEL_SOURCES = ("search_kernel.hpp", "search_team.hpp", "device_common.hpp", "kernels.hpp", "common.hpp", "search_plain.hip")
 
 
 def kernel_sources_hash():
@@ -341,11 +341,11 @@ def main():
         # HBM bytes per launch from the PMC passes of tools/collect_profiles.sh: reported only when they were measured on
         # this very kernel code (hash of its sources), at this ef and on this workload size
         traffic, traffic_note = None, "no counter measurement of this kernel code in profiles/pmc_traffic.json"
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json" if args.config == "c2" else f"pmc_traffic_{args.config}.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if args.config == "c2" and tj.get("kernel_sources_sha256_16") == kernel_sources_hash() and tj.get("ef_search") == ef and tj.get("n") == N and tj.get("queries") == Q:
+                if tj.get("kernel_sources_sha256_16") == kernel_sources_hash() and tj.get("ef_search") == ef and tj.get("n") == N and tj.get("queries") == Q:
                     traffic = tj.get("hbm_bytes_per_launch")
                     traffic_note = f"{tj.get('kernel')}, measured by {tj.get('command')}"
             except Exception:

@@ -12,18 +12,20 @@ from bench import kernel_sources_hash
 def newest(pattern):
     return max(glob.glob(pattern), key=os.path.getmtime)
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-src = f"gpurun_out/prof_{tag}"
+# usage: summarize_profiles.py <tag> [config]
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+cfg = sys.argv[2] if len(sys.argv) > 2 else "c2"
+src = f"gpurun_out/prof_{tag}_{cfg}"
 os.makedirs("profiles", exist_ok=True)
 last_json = lambda p: json.loads(open(p).read().strip().splitlines()[-1])
 bench = last_json(f"{src}/trace.json"); bench2 = last_json(f"{src}/trace2.json")
 ef = bench["config"]["ef_search"]
-pre = f"profiles/{tag}_bench_ef{ef}"
+pre = f"profiles/{tag}_bench_ef{ef}" if cfg == "c2" else f"profiles/{tag}_bench_{cfg}_ef{ef}"
 
 def trace(which, b):
     stats = pd.read_csv(newest(f"{src}/{which}/*/*_kernel_stats.csv"))
     tr = pd.read_csv(newest(f"{src}/{which}/*/*_kernel_trace.csv"))
-    sk = tr[tr.Kernel_Name.str.contains(r"search_kernel<0")].copy()
+    sk = tr[tr.Kernel_Name.str.contains(r"search_kernel<0|search_team_kernel<")].copy()
     sk["Duration_us"] = (sk.End_Timestamp - sk.Start_Timestamp) / 1e3
     main = sk.groupby("Kernel_Name").Duration_us.sum().idxmax()
     timed = sk[sk.Kernel_Name == main].sort_values("Start_Timestamp").tail(b["steps"]).copy()
@@ -50,16 +52,16 @@ for t, d in ev:
 def pmc(which, names=None):
     df = pd.read_csv(newest(f"{src}/{which}/*/*_counter_collection.csv"))
     k = df[df.Kernel_Name == main_name]
-    last = sorted(k.Dispatch_Id.unique())[-4:]
+    last = sorted(k.Dispatch_Id.unique())[-4:]          # timed launches (the last ones of the run)
     g = k[k.Dispatch_Id.isin(last)].groupby(["Dispatch_Id", "Counter_Name"]).Counter_Value.sum().groupby("Counter_Name").mean()
     return {n: float(v) for n, v in g.items()}, len(last)
 
 f1, n1 = pmc("fetch"); w1, _ = pmc("write"); f2, _ = pmc("fetch2"); w2, _ = pmc("write2")
 hbm1 = (2 * f1["FETCH_SIZE"] + w1["WRITE_SIZE"]) * 1024; hbm2 = (2 * f2["FETCH_SIZE"] + w2["WRITE_SIZE"]) * 1024
 lone_us = float(timed.Duration_us.mean())
-N = int(bench["config"]["workload"].split(":")[1].split("x")[0].strip()); Q = int(bench["config"]["workload"].split("fp32")[1].split("-query")[0].split(",")[-1].strip())
+N = int(bench["config"]["total_rows"]) // max(1, int(bench["config"]["shards"])); Q = int(bench["config"]["workload"].split("fp32")[1].split("-query")[0].split(",")[-1].strip())
 out = {
-    "command": f"tools/collect_profiles.sh {tag} {ef}  (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, one pass each, over python3 bench.py --ef {ef} --no-cpu-baseline with --streams 1 and with the default streams)",
+    "command": f"tools/collect_profiles.sh {tag} {ef} {cfg}  (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, one pass each, over python3 bench.py --config {cfg} --ef {ef} --no-cpu-baseline with --streams 1 and with the default streams; the timed steps rotate through {bench['config'].get('query_batches', 1)} distinct query batches)",
     "kernel": main_name, "kernel_sources_sha256_16": kernel_sources_hash(), "ef_search": ef, "n": N, "queries": Q, "launches_averaged": n1,
     "FETCH_SIZE_KB": f1["FETCH_SIZE"], "WRITE_SIZE_KB": w1["WRITE_SIZE"],
     "correction": "gfx950 FETCH_SIZE counts 64 B per 128-B request of a 16-B-per-lane read, so it is doubled; WRITE_SIZE is taken as is",
@@ -71,9 +73,14 @@ out = {
                    "share_of_span_with_two_launches_running": both / span,
                    "bench_ms_per_step": bench2["ms_per_step"], "bench_value_qps": bench2["value"],
                    "hbm_GBps": hbm2 / (bench2["ms_per_step"] * 1e3) / 1e3, "frac_of_8TBps": hbm2 / (bench2["ms_per_step"] * 1e3) / 1e3 / 8000},
-    "round": 2,
+    "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_query"] * Q,
+    "round": 3,
 }
-json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
+out["traffic_over_algorithmic"] = hbm1 / out["algorithmic_bytes_per_launch"]
+json.dump(out, open("profiles/pmc_traffic.json" if cfg == "c2" else f"profiles/pmc_traffic_{cfg}.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
+if not glob.glob(f"{src}/sq/*/*_counter_collection.csv"):
+    sys.exit(0)
 sq, _ = pmc("sq"); sq2, _ = pmc("sq2"); gr, _ = pmc("grbm")
 waves = sq["SQ_WAVES"]
 cnt = {"kernel": main_name, "kernel_sources_sha256_16": kernel_sources_hash(), "launch": f"{int(waves)} wavefronts (one per query), lone launches (--streams 1)",
