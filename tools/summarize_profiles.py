@@ -18,7 +18,9 @@ cfg = sys.argv[2] if len(sys.argv) > 2 else "c2"
 src = f"gpurun_out/prof_{tag}_{cfg}"
 os.makedirs("profiles", exist_ok=True)
 last_json = lambda p: json.loads(open(p).read().strip().splitlines()[-1])
-bench = last_json(f"{src}/trace.json"); bench2 = last_json(f"{src}/trace2.json")
+bench = last_json(f"{src}/trace.json")
+have2 = os.path.exists(f"{src}/trace2.json") and os.path.exists(f"{src}/fetch2.json")     # the overlapped passes may be left out
+bench2 = last_json(f"{src}/trace2.json") if have2 else bench
 ef = bench["config"]["ef_search"]
 pre = f"profiles/{tag}_bench_ef{ef}" if cfg == "c2" else f"profiles/{tag}_bench_{cfg}_ef{ef}"
 
@@ -33,7 +35,7 @@ def trace(which, b):
 
 stats, sk, main_name, timed = trace("trace", bench)
 stats.to_csv(f"{pre}_lone_kernel_stats.csv", index=False)
-stats2, sk2, main2, timed2 = trace("trace2", bench2)
+stats2, sk2, main2, timed2 = trace("trace2" if have2 else "trace", bench2)
 stats2.to_csv(f"{pre}_overlapped_kernel_stats.csv", index=False)
 assert main2 == main_name
 t0 = timed2.Start_Timestamp.min()
@@ -56,7 +58,7 @@ def pmc(which, names=None):
     g = k[k.Dispatch_Id.isin(last)].groupby(["Dispatch_Id", "Counter_Name"]).Counter_Value.sum().groupby("Counter_Name").mean()
     return {n: float(v) for n, v in g.items()}, len(last)
 
-f1, n1 = pmc("fetch"); w1, _ = pmc("write"); f2, _ = pmc("fetch2"); w2, _ = pmc("write2")
+f1, n1 = pmc("fetch"); w1, _ = pmc("write"); f2, _ = pmc("fetch2" if have2 else "fetch"); w2, _ = pmc("write2" if have2 else "write")
 hbm1 = (2 * f1["FETCH_SIZE"] + w1["WRITE_SIZE"]) * 1024; hbm2 = (2 * f2["FETCH_SIZE"] + w2["WRITE_SIZE"]) * 1024
 lone_us = float(timed.Duration_us.mean())
 N = int(bench["config"]["total_rows"]) // max(1, int(bench["config"]["shards"])); Q = int(bench["config"]["workload"].split("fp32")[1].split("-query")[0].split(",")[-1].strip())
@@ -74,6 +76,7 @@ out = {
                    "bench_ms_per_step": bench2["ms_per_step"], "bench_value_qps": bench2["value"],
                    "hbm_GBps": hbm2 / (bench2["ms_per_step"] * 1e3) / 1e3, "frac_of_8TBps": hbm2 / (bench2["ms_per_step"] * 1e3) / 1e3 / 8000},
     "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_query"] * Q,
+    "overlapped_passes_collected": have2,
     "round": 3,
 }
 out["traffic_over_algorithmic"] = hbm1 / out["algorithmic_bytes_per_launch"]
