@@ -78,7 +78,7 @@ CONFIGS = {
                 metric_name="queries/sec at recall@10>=0.95 (1M x 128 L2, uniform(0, 1) stress variant)", shape="uniform stress"),
     "c2": dict(n=1_000_000, dim=128, queries=10_000, metric=2, centres=4096, seed=0xC2, efs=[16, 32, 64, 96, 128, 144, 160, 176, 192, 224, 256],
                metric_name="queries/sec at recall@10>=0.95 (1M x 128 L2)", shape="SIFT1M-shape"),
-    "c3": dict(n=1_000_000, dim=960, queries=1_000, metric=0, centres=1024, seed=0xC3, efs=[64, 128, 192, 256, 384, 512], streams=6,
+    "c3": dict(n=1_000_000, dim=960, queries=1_000, metric=0, centres=1024, seed=0xC3, efs=[64, 128, 192, 256, 384, 416, 448, 480, 512], streams=6,
                metric_name="queries/sec at recall@10>=0.95 (1M x 960 cosine)", shape="GIST-shape"),
     "c5": dict(n=12_500_000, dim=96, queries=10_000, metric=2, centres=4096, seed=0xC5, efs=[32, 64, 128, 256],
                metric_name="queries/sec (100M x 96 L2 over 8 shards), recall@10 reported", shape="Deep100M-shape"),

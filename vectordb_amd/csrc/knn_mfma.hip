@@ -122,7 +122,7 @@ __device__ __forceinline__ void knn_admit_tile(const GraphView& gv, const float 
             const int jj = __ffs(need) - 1; need &= need - 1;
             float nt; uint32_t ni;
             knn_compact<KP, (int)CAP>(gv, cnt, buf, qbase + jj, nt, ni);
-            if (j == jj) { thr = nt; thr_row = ni; }
+            if (j == jj && nt <= thr) { thr = nt; thr_row = ni; }      // (fewer than KP held: +inf, the bound stays)
         }
         if (m != 0) {                                          // keys still waiting face the renewed bound
 #pragma unroll
@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(256) knn_split_queries_kernel(const float* __r
 template <int KS, int KNN_KP, int WPB>
 __global__ void __launch_bounds__(64 * WPB) knn_bf16_kernel(GraphView gv, const __bf16* __restrict__ qh, const __bf16* __restrict__ ql, uint32_t nq,
                                                       const float* __restrict__ centre, const float* __restrict__ scale, const float* __restrict__ bias,
-                                                      uint32_t* __restrict__ out_slots, float* __restrict__ out_thr, uint32_t n_chunks) {
+                                                      uint32_t* __restrict__ out_slots, float* __restrict__ out_thr, uint32_t n_chunks, const float* __restrict__ init_thr = nullptr) {
     constexpr int K = 16 * KS, LDB = K + 8;                    // bf16 per tile row, padded by 16 bytes: conflict-free 16-byte reads
     constexpr int KNN_CAP = KnnBuf<KNN_KP>::CAP;
     constexpr int MQB = 32 * WPB;                              // queries per block: 32 per wave
@@ -367,6 +367,7 @@ __global__ void __launch_bounds__(64 * WPB) knn_bf16_kernel(GraphView gv, const 
     }
     if (tid < MQB) cnt[tid] = 0;
     float thr = INF_F; uint32_t thr_row = NONE32;  // admission bound of this lane's query: key and row of its KP-th candidate
+    if (init_thr && q < nq) thr = init_thr[q];     // (diagnostic: a bound known beforehand)
 
     const uint32_t per = (((gv.n + n_chunks - 1) / n_chunks) + MT - 1) / MT * MT;
     const uint32_t r_begin = blockIdx.x * per, r_end = min(gv.n, r_begin + per);
@@ -723,6 +724,25 @@ __global__ void __launch_bounds__(256, 2) knn_bf16_long_kernel(GraphView gv, con
     }
 }
 
+// Diagnostic (VDB_KNN_ORACLE_BOUND): the tightest bound a query can start from — its strict k-th key, in the candidate
+// pass's key space, widened by 1e-3 — computed from a finished call's results.
+__global__ void __launch_bounds__(64) knn_oracle_bound_kernel(GraphView gv, const float* __restrict__ queries, const float* __restrict__ centre, uint32_t top_k,
+                                                             const vdb_scored_point* __restrict__ out, const uint32_t* __restrict__ out_n, float* __restrict__ init_thr) {
+    const uint32_t q = blockIdx.x; const int lane = lane_id();
+    float qn2 = 0.f;
+    for (uint32_t i = lane; i < gv.dim; i += WAVE) { const float d = queries[(size_t)q * gv.dim + i] - (gv.metric == VDB_EUCLIDEAN ? centre[i] : 0.f); qn2 = __builtin_fmaf(d, d, qn2); }
+    qn2 = group_sum<64>(qn2);
+    if (lane != 0) return;
+    float b = INF_F;
+    if (out_n[q] >= top_k) {
+        const float kth = out[(size_t)q * top_k + top_k - 1].sort_key;
+        if (gv.metric == VDB_EUCLIDEAN) b = kth * kth * 1.001f - qn2;
+        else if (gv.metric == VDB_DOT) b = kth + 1e-3f * __builtin_fabsf(kth);
+        else b = (kth - 1.0f) * __builtin_sqrtf(qn2) * (kth < 1.0f ? 0.999f : 1.001f);
+    }
+    init_thr[q] = b;
+}
+
 // One wave per query: strict scores of the candidate slots, ranked by (sort_key, id).
 struct TopKList {
     float* key; uint64_t* id; float* raw; uint32_t n, cap;
@@ -1012,6 +1032,24 @@ static void run_exact_knn_mfma(const GraphView& g, const float* queries, uint32_
     hipLaunchKernelGGL(knn_rerank_kernel, dim3(nq), dim3(64), lds, st, g, queries, top_k, slots, n_chunks * kp, thr, n_chunks,
                        g.metric == VDB_EUCLIDEAN ? centre : nullptr, max_norm2, verify ? flags : nullptr, max_norm2 + 1, out, out_n);
     VDB_HIP(hipGetLastError());
+    if (bf16 && std::getenv("VDB_KNN_ORACLE_BOUND") && g.stride > 64 && g.stride <= 128 && kp == 16) {
+        // diagnostic: the same candidate pass again, every query starting from the bound an oracle would give it; timed
+        float* init = nullptr; VDB_HIP(hipMalloc(&init, (size_t)nq * 4));
+        hipLaunchKernelGGL(knn_oracle_bound_kernel, dim3(nq), dim3(64), 0, st, g, queries, centre, top_k, out, out_n, init);
+        constexpr int KS = 8, WPB = 4, K = 16 * KS, MQB = 32 * WPB;
+        const size_t l2 = (size_t)KNN_BF16_BUFFERS * ((size_t)2 * MT * (K + 8) * 2 + 2 * MT * 4) + MQB * 4 + (size_t)MQB * KnnBuf<16>::CAP * 8;
+        hipEvent_t e0, e1, e2; VDB_HIP(hipEventCreate(&e0)); VDB_HIP(hipEventCreate(&e1)); VDB_HIP(hipEventCreate(&e2));
+        VDB_HIP(hipEventRecord(e0, st));
+        hipLaunchKernelGGL((knn_bf16_kernel<KS, 16, WPB>), dim3(n_chunks, (nq + MQB - 1) / MQB), dim3(64 * WPB), l2, st, g, qh, ql, nq, centre, scale, bias, slots, thr, n_chunks, (const float*)nullptr);
+        VDB_HIP(hipEventRecord(e1, st));
+        hipLaunchKernelGGL((knn_bf16_kernel<KS, 16, WPB>), dim3(n_chunks, (nq + MQB - 1) / MQB), dim3(64 * WPB), l2, st, g, qh, ql, nq, centre, scale, bias, slots, thr, n_chunks, (const float*)init);
+        VDB_HIP(hipEventRecord(e2, st)); VDB_HIP(hipEventSynchronize(e2));
+        float a = 0, b = 0; VDB_HIP(hipEventElapsedTime(&a, e0, e1)); VDB_HIP(hipEventElapsedTime(&b, e1, e2));
+        fprintf(stderr, "[knn] candidate pass %u chunks: %.3f ms from +inf bounds, %.3f ms from oracle bounds\n", n_chunks, a, b);
+        VDB_HIP(hipFree(init));
+        hipLaunchKernelGGL(knn_rerank_kernel, dim3(nq), dim3(64), lds, st, g, queries, top_k, slots, n_chunks * kp, thr, n_chunks,
+                           g.metric == VDB_EUCLIDEAN ? centre : nullptr, max_norm2, (uint32_t*)nullptr, max_norm2 + 1, out, out_n);
+    }
     if (verify) {
         const size_t fl = (size_t)g.stride * 4 + (size_t)FB_WAVES * top_k * 16 + FB_WAVES * 4;
         hipLaunchKernelGGL(knn_fallback_kernel, dim3(std::min<uint32_t>(nq, 1024u)), dim3(64 * FB_WAVES), fl, st, g, queries, top_k, flags, max_norm2 + 1, out, out_n);
