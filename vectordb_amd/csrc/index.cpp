@@ -696,6 +696,11 @@ void vdb_index::search_batch_dev(const float* d_q, size_t nq, size_t top_k, size
                                  vdb_query_stats* d_stats, hipStream_t s, const FilterArgs* fa) {
     if (nq == 0) return;
     std::lock_guard<std::mutex> lk(mu);
+    search_dev_locked(d_q, nq, top_k, ef_search, d_out, d_out_n, d_stats, s, fa);
+}
+
+void vdb_index::search_dev_locked(const float* d_q, size_t nq, size_t top_k, size_t ef_search, vdb_scored_point* d_out, uint32_t* d_out_n,
+                                  vdb_query_stats* d_stats, hipStream_t s, const FilterArgs* fa) {
     use_device();
     if (!s) s = stream;
     const size_t ef_ = ef_search ? ef_search : ef;
@@ -738,8 +743,12 @@ void vdb_index::exact_knn(const float* q, size_t nq, size_t top_k, bool dev, vdb
     DevBuf<uint32_t>& words = s_knn_words_by_stream[s]; DevBuf<vdb_scored_point>& lists = s_knn_by_stream[s];
     if (mfma) words.reserve(knn_mfma_scratch_words(g.n, (uint32_t)nq, g.stride), s, false);
     else lists.reserve(nq * chunks * top_k, s, false);
+    // A graph over all rows answers first (a short beam): its k-th key bounds the true one, and the candidate pass that
+    // starts from that bound admits a fraction of the rows it admits from +inf.  The exact answer does not depend on it.
+    const bool hint = mfma && !rowmap && entry_point && ids.size() >= 65536 && top_k <= MAX_EF / 4 && !std::getenv("VDB_KNN_NO_HINT");
     auto run = [&](const float* dq, vdb_scored_point* dout, uint32_t* dn) {
-        if (mfma) launch_exact_knn_mfma(g, dq, (uint32_t)nq, (uint32_t)top_k, dout, dn, words.p, s);
+        if (hint) search_dev_locked(dq, nq, top_k, std::max<size_t>(32, 2 * top_k), dout, dn, nullptr, s, nullptr);
+        if (mfma) launch_exact_knn_mfma(g, dq, (uint32_t)nq, (uint32_t)top_k, dout, dn, words.p, s, hint);
         else launch_exact_knn(g, dq, (uint32_t)nq, (uint32_t)top_k, dout, dn, lists.p, chunks, s);
     };
     if (dev) { run(q, out, out_n); return; }

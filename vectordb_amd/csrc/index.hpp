@@ -138,6 +138,9 @@ struct vdb_index {
     struct FilterArgs { int mode = vdb::MODE_SEARCH; const vdb::FilterBits* bits = nullptr; uint32_t entry_slot = vdb::NONE32; };
     void search_batch(const float* q, size_t nq, size_t top_k, size_t ef_search, const FilterArgs& fa,
                       vdb_scored_point* out, uint32_t* out_n, vdb_query_stats* stats);
+    // search_batch_dev with the index mutex already held
+    void search_dev_locked(const float* d_q, size_t nq, size_t top_k, size_t ef_search, vdb_scored_point* d_out, uint32_t* d_out_n,
+                           vdb_query_stats* d_stats, hipStream_t s, const FilterArgs* fa);
     void search_batch_dev(const float* d_q, size_t nq, size_t top_k, size_t ef_search, vdb_scored_point* d_out, uint32_t* d_out_n,
                           vdb_query_stats* d_stats, hipStream_t s, const FilterArgs* fa = nullptr);
     // rowmap (device, n_rows live slots): exact k-NN over those slots only, read where they lie

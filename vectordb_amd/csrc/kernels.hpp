@@ -118,8 +118,10 @@ uint32_t exact_knn_chunks(uint32_t n);
 // FAST exact k-NN: fp32 MFMA candidate pass + strict re-rank (knn_mfma.hip).  scratch holds knn_mfma_scratch_words() dwords.
 bool knn_mfma_supported(const GraphView& g, uint32_t top_k);
 size_t knn_mfma_scratch_words(uint32_t n, uint32_t nq, uint32_t stride);
+// hint: out / out_n already hold an approximate answer of top_k actual rows per query (the graph's); the candidate pass starts
+// from the bounds it gives.  The result does not depend on it.
 void launch_exact_knn_mfma(const GraphView& g, const float* queries, uint32_t nq, uint32_t top_k, vdb_scored_point* out, uint32_t* out_n,
-                           uint32_t* scratch, hipStream_t s);
+                           uint32_t* scratch, hipStream_t s, bool hint = false);
 // The same pass on a static scratch area inside the library's code object (no allocation; 16 MiB per GPU, shared by every
 // call on that GPU): throws when 2 * rows + queries * candidates-per-chunk words do not fit.
 void launch_exact_knn_mfma_static(const GraphView& g, const float* queries, uint32_t nq, uint32_t top_k, vdb_scored_point* out, uint32_t* out_n,

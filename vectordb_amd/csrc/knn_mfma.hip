@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(256) knn_split_queries_kernel(const float* __r
 template <int KS, int KNN_KP, int WPB>
 __global__ void __launch_bounds__(64 * WPB) knn_bf16_kernel(GraphView gv, const __bf16* __restrict__ qh, const __bf16* __restrict__ ql, uint32_t nq,
                                                       const float* __restrict__ centre, const float* __restrict__ scale, const float* __restrict__ bias,
-                                                      uint32_t* __restrict__ out_slots, float* __restrict__ out_thr, uint32_t n_chunks, const float* __restrict__ init_thr = nullptr) {
+                                                      uint32_t* __restrict__ out_slots, float* __restrict__ out_thr, uint32_t n_chunks, const float* __restrict__ init_thr) {
     constexpr int K = 16 * KS, LDB = K + 8;                    // bf16 per tile row, padded by 16 bytes: conflict-free 16-byte reads
     constexpr int KNN_CAP = KnnBuf<KNN_KP>::CAP;
     constexpr int MQB = 32 * WPB;                              // queries per block: 32 per wave
@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(64 * WPB) knn_bf16_kernel(GraphView gv, const 
     }
     if (tid < MQB) cnt[tid] = 0;
     float thr = INF_F; uint32_t thr_row = NONE32;  // admission bound of this lane's query: key and row of its KP-th candidate
-    if (init_thr && q < nq) thr = init_thr[q];     // (diagnostic: a bound known beforehand)
+    if (init_thr && q < nq) thr = init_thr[q];     // a bound known beforehand (the graph's answer)
 
     const uint32_t per = (((gv.n + n_chunks - 1) / n_chunks) + MT - 1) / MT * MT;
     const uint32_t r_begin = blockIdx.x * per, r_end = min(gv.n, r_begin + per);
@@ -598,7 +598,7 @@ constexpr int KC2 = 32, LDK2 = KC2 + 8;
 template <int KNN_KP>
 __global__ void __launch_bounds__(256, 2) knn_bf16_long_kernel(GraphView gv, const __bf16* __restrict__ qh, const __bf16* __restrict__ ql, uint32_t kq, uint32_t nq,
                                                            const float* __restrict__ centre, const float* __restrict__ scale, const float* __restrict__ bias,
-                                                           uint32_t* __restrict__ out_slots, float* __restrict__ out_thr, uint32_t n_chunks) {
+                                                           uint32_t* __restrict__ out_slots, float* __restrict__ out_thr, uint32_t n_chunks, const float* __restrict__ init_thr) {
     constexpr int KNN_CAP = KnnBuf<KNN_KP>::CAP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __bf16* Ah = reinterpret_cast<__bf16*>(smem);                                // LT x LDK2 high parts
@@ -621,6 +621,7 @@ __global__ void __launch_bounds__(256, 2) knn_bf16_long_kernel(GraphView gv, con
 
     if (tid < MQ) cnt[tid] = 0;
     float thr = INF_F; uint32_t thr_row = NONE32;  // admission bound of this lane's query: key and row of its KP-th candidate
+    if (init_thr && qin) thr = init_thr[q];        // a bound known beforehand (the graph's answer)
     const uint32_t per = (((gv.n + n_chunks - 1) / n_chunks) + LT - 1) / LT * LT;
     const uint32_t r_begin = blockIdx.x * per, r_end = min(gv.n, r_begin + per);
     const int lrow = tid >> 1, lhalf = tid & 1;          // loader: thread t brings 16 floats of tile row t / 2
@@ -724,10 +725,15 @@ __global__ void __launch_bounds__(256, 2) knn_bf16_long_kernel(GraphView gv, con
     }
 }
 
-// Diagnostic (VDB_KNN_ORACLE_BOUND): the tightest bound a query can start from — its strict k-th key, in the candidate
-// pass's key space, widened by 1e-3 — computed from a finished call's results.
-__global__ void __launch_bounds__(64) knn_oracle_bound_kernel(GraphView gv, const float* __restrict__ queries, const float* __restrict__ centre, uint32_t top_k,
-                                                             const vdb_scored_point* __restrict__ out, const uint32_t* __restrict__ out_n, float* __restrict__ init_thr) {
+// A bound every query can start its candidate pass from when `out` already holds an approximate answer (the graph's):
+// top_k actual rows, so the true k-th key is at or below their k-th key.  In the candidate pass's key space, widened by
+// three times the error budget of the verification (the rows found must pass under it by their approximate keys, and the
+// verification must still see a gap of one budget above the strict k-th key); +inf where the answer holds fewer than top_k
+// rows.  ORACLE (diagnostic VDB_KNN_ORACLE_BOUND): the k-th key widened by 1e-3 only.
+template <bool ORACLE>
+__global__ void __launch_bounds__(64) knn_bound_kernel(GraphView gv, const float* __restrict__ queries, const float* __restrict__ centre, uint32_t top_k,
+                                                      const uint32_t* __restrict__ max_norm2,
+                                                      const vdb_scored_point* __restrict__ out, const uint32_t* __restrict__ out_n, float* __restrict__ init_thr) {
     const uint32_t q = blockIdx.x; const int lane = lane_id();
     float qn2 = 0.f;
     for (uint32_t i = lane; i < gv.dim; i += WAVE) { const float d = queries[(size_t)q * gv.dim + i] - (gv.metric == VDB_EUCLIDEAN ? centre[i] : 0.f); qn2 = __builtin_fmaf(d, d, qn2); }
@@ -736,9 +742,17 @@ __global__ void __launch_bounds__(64) knn_oracle_bound_kernel(GraphView gv, cons
     float b = INF_F;
     if (out_n[q] >= top_k) {
         const float kth = out[(size_t)q * top_k + top_k - 1].sort_key;
-        if (gv.metric == VDB_EUCLIDEAN) b = kth * kth * 1.001f - qn2;
-        else if (gv.metric == VDB_DOT) b = kth + 1e-3f * __builtin_fabsf(kth);
-        else b = (kth - 1.0f) * __builtin_sqrtf(qn2) * (kth < 1.0f ? 0.999f : 1.001f);
+        const float E = 1.220703125e-4f + (float)gv.dim * 1.1920929e-7f + 1e-5f;
+        const float xm = __builtin_sqrtf(__uint_as_float(*max_norm2)), qn = __builtin_sqrtf(qn2);
+        if (ORACLE) {
+            if (gv.metric == VDB_EUCLIDEAN) b = kth * kth * 1.001f - qn2;
+            else if (gv.metric == VDB_DOT) b = kth + 1e-3f * __builtin_fabsf(kth);
+            else b = (kth - 1.0f) * qn * (kth < 1.0f ? 0.999f : 1.001f);
+        } else {
+            if (gv.metric == VDB_EUCLIDEAN) b = kth * kth * 1.00003f - qn2 + 3.0f * E * (qn + xm) * (qn + xm);
+            else if (gv.metric == VDB_DOT) b = kth + 3.0f * E * qn * xm;
+            else b = (kth - 1.0f) * qn + 3.0f * E * qn;
+        }
     }
     init_thr[q] = b;
 }
@@ -943,7 +957,7 @@ uint32_t launch_mfma(const GraphView& g, const float* queries, uint32_t nq, cons
 // padded row length of the bf16 planes of the queries
 inline uint32_t knn_bf16_k(uint32_t stride) { return stride <= 64 ? 64u : stride <= 128 ? 128u : stride <= 256 ? 256u : (stride + 63u) / 64u * 64u; }
 template <int KS, int KP, int WPB>
-uint32_t launch_bf16(const GraphView& g, const __bf16* qh, const __bf16* ql, uint32_t nq, const float* centre, const float* scale, const float* bias, uint32_t* slots, float* thr, uint32_t max_chunks, hipStream_t st) {
+uint32_t launch_bf16(const GraphView& g, const __bf16* qh, const __bf16* ql, uint32_t nq, const float* centre, const float* scale, const float* bias, uint32_t* slots, float* thr, const float* init, uint32_t max_chunks, hipStream_t st) {
     constexpr int K = 16 * KS, MQB = 32 * WPB;
     const size_t lds = (size_t)KNN_BF16_BUFFERS * ((size_t)2 * MT * (K + 8) * 2 + 2 * MT * 4) + MQB * 4 + (size_t)MQB * KnnBuf<KP>::CAP * 8;
     int dev = 0, cus = 256, per_cu = 1;
@@ -951,18 +965,18 @@ uint32_t launch_bf16(const GraphView& g, const __bf16* qh, const __bf16* ql, uin
     VDB_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     VDB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, knn_bf16_kernel<KS, KP, WPB>, 64 * WPB, lds));
     const uint32_t n_chunks = pick_chunks(g.n, nq, MQB, (uint32_t)std::max(1, cus) * (uint32_t)std::max(1, per_cu), max_chunks);
-    hipLaunchKernelGGL((knn_bf16_kernel<KS, KP, WPB>), dim3(n_chunks, (nq + MQB - 1) / MQB), dim3(64 * WPB), lds, st, g, qh, ql, nq, centre, scale, bias, slots, thr, n_chunks);
+    hipLaunchKernelGGL((knn_bf16_kernel<KS, KP, WPB>), dim3(n_chunks, (nq + MQB - 1) / MQB), dim3(64 * WPB), lds, st, g, qh, ql, nq, centre, scale, bias, slots, thr, n_chunks, init);
     return n_chunks;
 }
 template <int KP>
-uint32_t launch_bf16_any(const GraphView& g, const __bf16* qh, const __bf16* ql, uint32_t nq, const float* centre, const float* scale, const float* bias, uint32_t* slots, float* thr, uint32_t max_chunks, hipStream_t st) {
+uint32_t launch_bf16_any(const GraphView& g, const __bf16* qh, const __bf16* ql, uint32_t nq, const float* centre, const float* scale, const float* bias, uint32_t* slots, float* thr, const float* init, uint32_t max_chunks, hipStream_t st) {
     const bool force_long = std::getenv("VDB_KNN_LONG") != nullptr;   // diagnostic: the chunked kernel on short rows
-    if (!force_long && g.stride <= 64) return launch_bf16<4, KP, 4>(g, qh, ql, nq, centre, scale, bias, slots, thr, max_chunks, st);
-    if (!force_long && g.stride <= 128) return launch_bf16<8, KP, 4>(g, qh, ql, nq, centre, scale, bias, slots, thr, max_chunks, st);
-    if (!force_long && g.stride <= 256) return launch_bf16<16, KP, 8>(g, qh, ql, nq, centre, scale, bias, slots, thr, max_chunks, st);
+    if (!force_long && g.stride <= 64) return launch_bf16<4, KP, 4>(g, qh, ql, nq, centre, scale, bias, slots, thr, init, max_chunks, st);
+    if (!force_long && g.stride <= 128) return launch_bf16<8, KP, 4>(g, qh, ql, nq, centre, scale, bias, slots, thr, init, max_chunks, st);
+    if (!force_long && g.stride <= 256) return launch_bf16<16, KP, 8>(g, qh, ql, nq, centre, scale, bias, slots, thr, init, max_chunks, st);
     const size_t lds = (size_t)2 * LT * LDK2 * 2 + 2 * LT * 4 + MQ * 4 + (size_t)MQ * KnnBuf<KP>::CAP * 8 + (size_t)knn_bf16_k(g.stride) * 4;
     const uint32_t n_chunks = pick_chunks(g.n, nq, MQ, resident_blocks(knn_bf16_long_kernel<KP>, lds), max_chunks);
-    hipLaunchKernelGGL((knn_bf16_long_kernel<KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, qh, ql, knn_bf16_k(g.stride), nq, centre, scale, bias, slots, thr, n_chunks);
+    hipLaunchKernelGGL((knn_bf16_long_kernel<KP>), dim3(n_chunks, (nq + MQ - 1) / MQ), dim3(256), lds, st, g, qh, ql, knn_bf16_k(g.stride), nq, centre, scale, bias, slots, thr, n_chunks, init);
     return n_chunks;
 }
 template <int KP>
@@ -992,8 +1006,10 @@ size_t knn_mfma_scratch_words(uint32_t n, uint32_t nq, uint32_t stride) {
 
 // scratch: [centre K][scale n][bias n][query planes: 2 x nq x K bf16][largest squared row norm: 4][flags nq]
 //          [candidate slots: nq x max_chunks x KP][final bounds: nq x max_chunks]
+// hint: `out` / `out_n` hold an approximate answer (top_k actual rows per query, the graph's): every query's candidate
+// pass then starts from the bound that answer gives instead of +inf (knn_bound_kernel), which spares most admissions.
 static void run_exact_knn_mfma(const GraphView& g, const float* queries, uint32_t nq, uint32_t top_k, vdb_scored_point* out, uint32_t* out_n,
-                               uint32_t* scratch, uint32_t max_chunks, hipStream_t st) {
+                               uint32_t* scratch, uint32_t max_chunks, hipStream_t st, bool hint) {
     const uint32_t kpad = knn_bf16_k(g.stride);
     const bool bf16 = !std::getenv("VDB_KNN_FP32");            // diagnostic: the fp32 MFMA kernels the bf16 ones are measured against
     float* centre = reinterpret_cast<float*>(scratch);
@@ -1015,12 +1031,19 @@ static void run_exact_knn_mfma(const GraphView& g, const float* queries, uint32_
     VDB_HIP(hipGetLastError());
     const uint32_t kp = knn_kp(top_k);
     uint32_t n_chunks;
+    // the starting bounds share the words of the flag list, which is written only after the candidate pass has run
+    const float* init = nullptr;
+    if (bf16 && hint) {
+        hipLaunchKernelGGL(knn_bound_kernel<false>, dim3(nq), dim3(64), 0, st, g, queries, centre, top_k, max_norm2, out, out_n, reinterpret_cast<float*>(flags));
+        VDB_HIP(hipGetLastError());
+        init = reinterpret_cast<const float*>(flags);
+    }
     if (bf16) {
         const size_t cells = (size_t)nq * kpad;
         hipLaunchKernelGGL(knn_split_queries_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, queries, centre, nq, g.dim, kpad, qh, ql);
         VDB_HIP(hipGetLastError());
-        n_chunks = kp == 16 ? launch_bf16_any<16>(g, qh, ql, nq, centre, scale, bias, slots, thr, max_chunks, st)
-                            : launch_bf16_any<32>(g, qh, ql, nq, centre, scale, bias, slots, thr, max_chunks, st);
+        n_chunks = kp == 16 ? launch_bf16_any<16>(g, qh, ql, nq, centre, scale, bias, slots, thr, init, max_chunks, st)
+                            : launch_bf16_any<32>(g, qh, ql, nq, centre, scale, bias, slots, thr, init, max_chunks, st);
     } else {
         n_chunks = kp == 16 ? launch_mfma_any<16>(g, queries, nq, scale, bias, slots, thr, max_chunks, st)
                             : launch_mfma_any<32>(g, queries, nq, scale, bias, slots, thr, max_chunks, st);
@@ -1034,19 +1057,19 @@ static void run_exact_knn_mfma(const GraphView& g, const float* queries, uint32_
     VDB_HIP(hipGetLastError());
     if (bf16 && std::getenv("VDB_KNN_ORACLE_BOUND") && g.stride > 64 && g.stride <= 128 && kp == 16) {
         // diagnostic: the same candidate pass again, every query starting from the bound an oracle would give it; timed
-        float* init = nullptr; VDB_HIP(hipMalloc(&init, (size_t)nq * 4));
-        hipLaunchKernelGGL(knn_oracle_bound_kernel, dim3(nq), dim3(64), 0, st, g, queries, centre, top_k, out, out_n, init);
+        float* oinit = nullptr; VDB_HIP(hipMalloc(&oinit, (size_t)nq * 4));
+        hipLaunchKernelGGL(knn_bound_kernel<true>, dim3(nq), dim3(64), 0, st, g, queries, centre, top_k, max_norm2, out, out_n, oinit);
         constexpr int KS = 8, WPB = 4, K = 16 * KS, MQB = 32 * WPB;
         const size_t l2 = (size_t)KNN_BF16_BUFFERS * ((size_t)2 * MT * (K + 8) * 2 + 2 * MT * 4) + MQB * 4 + (size_t)MQB * KnnBuf<16>::CAP * 8;
         hipEvent_t e0, e1, e2; VDB_HIP(hipEventCreate(&e0)); VDB_HIP(hipEventCreate(&e1)); VDB_HIP(hipEventCreate(&e2));
         VDB_HIP(hipEventRecord(e0, st));
         hipLaunchKernelGGL((knn_bf16_kernel<KS, 16, WPB>), dim3(n_chunks, (nq + MQB - 1) / MQB), dim3(64 * WPB), l2, st, g, qh, ql, nq, centre, scale, bias, slots, thr, n_chunks, (const float*)nullptr);
         VDB_HIP(hipEventRecord(e1, st));
-        hipLaunchKernelGGL((knn_bf16_kernel<KS, 16, WPB>), dim3(n_chunks, (nq + MQB - 1) / MQB), dim3(64 * WPB), l2, st, g, qh, ql, nq, centre, scale, bias, slots, thr, n_chunks, (const float*)init);
+        hipLaunchKernelGGL((knn_bf16_kernel<KS, 16, WPB>), dim3(n_chunks, (nq + MQB - 1) / MQB), dim3(64 * WPB), l2, st, g, qh, ql, nq, centre, scale, bias, slots, thr, n_chunks, (const float*)oinit);
         VDB_HIP(hipEventRecord(e2, st)); VDB_HIP(hipEventSynchronize(e2));
         float a = 0, b = 0; VDB_HIP(hipEventElapsedTime(&a, e0, e1)); VDB_HIP(hipEventElapsedTime(&b, e1, e2));
         fprintf(stderr, "[knn] candidate pass %u chunks: %.3f ms from +inf bounds, %.3f ms from oracle bounds\n", n_chunks, a, b);
-        VDB_HIP(hipFree(init));
+        VDB_HIP(hipFree(oinit));
         hipLaunchKernelGGL(knn_rerank_kernel, dim3(nq), dim3(64), lds, st, g, queries, top_k, slots, n_chunks * kp, thr, n_chunks,
                            g.metric == VDB_EUCLIDEAN ? centre : nullptr, max_norm2, (uint32_t*)nullptr, max_norm2 + 1, out, out_n);
     }
@@ -1059,9 +1082,9 @@ static void run_exact_knn_mfma(const GraphView& g, const float* queries, uint32_
 
 // scratch: knn_mfma_scratch_words() dwords
 void launch_exact_knn_mfma(const GraphView& g, const float* queries, uint32_t nq, uint32_t top_k, vdb_scored_point* out, uint32_t* out_n,
-                           uint32_t* scratch, hipStream_t st) {
+                           uint32_t* scratch, hipStream_t st, bool hint) {
     if (nq == 0) return;
-    run_exact_knn_mfma(g, queries, nq, top_k, out, out_n, scratch, 64, st);
+    run_exact_knn_mfma(g, queries, nq, top_k, out, out_n, scratch, 64, st, hint);
 }
 
 // ---- the same pass on a scratch area that is part of the library's code object: nothing is allocated ----
@@ -1102,7 +1125,7 @@ void launch_exact_knn_mfma_static(const GraphView& g, const float* queries, uint
         throw Failure(err_arg("exact k-NN without allocation: 2 * rows + queries * (" + std::to_string(kp) + " + padded row length up to 256) = " + std::to_string(fixed + per_chunk) +
                               " words exceed the static scratch of " + std::to_string(KNN_STATIC_WORDS) + " words (16 MiB); use vdb_index_exact_knn_batch_dev"));
     const uint32_t max_chunks = (uint32_t)std::min<size_t>(64, (KNN_STATIC_WORDS - fixed) / per_chunk);
-    run_exact_knn_mfma(g, queries, nq, top_k, out, out_n, knn_static_scratch_ptr(), max_chunks, st);
+    run_exact_knn_mfma(g, queries, nq, top_k, out, out_n, knn_static_scratch_ptr(), max_chunks, st, false);
 }
 
 }  // namespace vdb
