@@ -3,7 +3,7 @@ summaries profiles/<tag>_exact_knn.json, profiles/<tag>_scan.json and the kernel
 import glob, json, os, sys
 import pandas as pd
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = f"gpurun_out/aux_{tag}"
 newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)
 last_json = lambda p: json.loads([l for l in open(p).read().strip().splitlines() if l.startswith("{")][-1])
