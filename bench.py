@@ -464,11 +464,11 @@ def bench_c4(args):
              "all_results_pass_filter": all_pass, "recall_at_10_vs_float64_brute_force": rec}
         if scanned:
             tf = 2.0 * Q * n_pass * D / (ms * 1e-3) / 1e12
-            # algorithmic flop (2 Q N D, fp32 products) against the fp32 matrix peak; the candidate pass issues three bf16
-            # MFMAs per product, priced against the bf16 peak beside it
-            r["roofline"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
-                             "peak_is": "fp32 MFMA; the pass runs as 3 bf16 MFMAs per product",
-                             "bf16_mfma": {"issued": 3 * tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": 3 * tf / MFMA_BF16_PEAK_TFLOPS},
+            # the candidate pass issues three bf16 MFMAs per fp32 product: priced against the dense bf16 matrix peak;
+            # the algorithmic rate (2 Q N D) is kept beside it
+            r["roofline"] = {"bound": "mfma", "achieved": 3 * tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": 3 * tf / MFMA_BF16_PEAK_TFLOPS,
+                             "peak_is": "dense bf16 MFMA; achieved = 3 bf16 products issued per fp32 product (bf16 split)",
+                             "fp32_equivalent_tflops": tf,
                              "hbm_bytes_algorithmic": 4.0 * n_pass * D + N / 8}
         else:
             b = float(st["rows_scored"].astype(np.float64).sum() * (4 * info["row_stride_floats"] + 0.125) + st["adj_entries"].astype(np.float64).sum() * 4 + st["expanded"].astype(np.float64).sum() * 8)

@@ -156,6 +156,41 @@ def test_filtered_search_on_device_buffers_equals_the_host_buffer_call(vdb, metr
     torch.cuda.synchronize()
 
 
+def test_more_streams_and_filters_than_the_library_remembers(vdb):
+    """24 filters on 24 streams queued back to back without a host synchronisation: the segment's cache keeps 16 compiled
+    filters and an index 16 streams' scratch, so entries are dropped while launches that read them are still queued."""
+    torch = pytest.importorskip("torch")
+    n, d, nq, k = 5000, 32, 300, 10
+    rng = np.random.default_rng(41)
+    x = rng.normal(size=(n, d)).astype(np.float32); q = rng.normal(size=(nq, d)).astype(np.float32)
+    seg = vdb.Segment(vdb.HNSWIndex(2, 16, 64, 16, d, seed=2, filter_mode=vdb.FilterMode.Masked))
+    seg.insert_batch_columns(x, {"cat": (np.arange(n) % 48).astype(np.int64), "half": (np.arange(n) % 2).astype(np.int64)})
+    V, F, Op = vdb.PayloadValue, vdb.Filter, vdb.ScalarComparisonOp
+    filters = [F.Match("cat", V.Int(c)) if c % 2 else F.And([F.Match("half", V.Int(0)), F.Compare("cat", Op.Lt, V.Int(c + 2))]) for c in range(24)]
+    want = [seg.search_batch(q, k, ef_search=64, filter=f) for f in filters]
+    want_knn = seg.hnsw().exact_knn_batch(q, k)
+    dev = torch.device("cuda", 0)
+    dq = torch.from_numpy(q).to(dev)
+    streams = [torch.cuda.Stream(device=dev) for _ in filters]
+    outs = [torch.zeros(nq * k * 16, dtype=torch.uint8, device=dev) for _ in filters]; cnts = [torch.full((nq,), -1, dtype=torch.int32, device=dev) for _ in filters]
+    kouts = [torch.zeros(nq * k * 16, dtype=torch.uint8, device=dev) for _ in filters]; kcnts = [torch.full((nq,), -1, dtype=torch.int32, device=dev) for _ in filters]
+    torch.cuda.synchronize()
+    for rnd in range(2):
+        for f, st, o, c, ko, kc in zip(filters, streams, outs, cnts, kouts, kcnts):
+            vdb.check(vdb.fn.segment_search_batch_dev(seg._h, dq.data_ptr(), nq, k, 64, f._h, o.data_ptr(), c.data_ptr(), None, st.cuda_stream))
+            vdb.check(vdb.fn.index_exact_knn_batch_dev(seg.hnsw()._h, dq.data_ptr(), nq, k, ko.data_ptr(), kc.data_ptr(), st.cuda_stream))
+    torch.cuda.synchronize()
+    for (w, wn), o, c, ko, kc in zip(want, outs, cnts, kouts, kcnts):
+        got = o.cpu().numpy().view(vdb.SCORED_DTYPE).reshape(nq, k); got_n = c.cpu().numpy().view(np.uint32)
+        assert np.array_equal(wn, got_n)
+        for i in range(nq):
+            assert np.array_equal(w["id"][i][: wn[i]], got["id"][i][: wn[i]])
+            assert np.array_equal(w["sort_key"][i][: wn[i]].view(np.uint32), got["sort_key"][i][: wn[i]].view(np.uint32))
+        gk = ko.cpu().numpy().view(vdb.SCORED_DTYPE).reshape(nq, k)
+        assert np.array_equal(kc.cpu().numpy().view(np.uint32), want_knn[1])
+        assert np.array_equal(gk["id"], want_knn[0]["id"])
+
+
 def test_payload_columns_build_the_same_segment_as_payload_objects(vdb):
     n, d = 2000, 16
     rng = np.random.default_rng(5)

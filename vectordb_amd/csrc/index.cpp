@@ -35,6 +35,21 @@ vdb_index::~vdb_index() {
     if (h_pin) (void)hipHostFree(h_pin);
 }
 
+vdb_index::StreamScratch& vdb_index::stream_scratch(hipStream_t s) const {
+    auto it = s_by_stream.find(s);
+    if (it == s_by_stream.end()) {
+        if (s_by_stream.size() >= STREAM_SCRATCH_MAX) {
+            auto victim = s_by_stream.begin();
+            for (auto c = s_by_stream.begin(); c != s_by_stream.end(); ++c) if (c->second.last_used < victim->second.last_used) victim = c;
+            VDB_HIP(hipDeviceSynchronize());          // kernels of the victim's stream may still use its buffers
+            s_by_stream.erase(victim);
+        }
+        it = s_by_stream.try_emplace(s).first;
+    }
+    it->second.last_used = ++s_stream_clock;
+    return it->second;
+}
+
 void* vdb_index::pinned(size_t bytes) const {
     if (bytes > h_pin_bytes) {
         if (h_pin) VDB_HIP(hipHostFree(h_pin));
@@ -714,7 +729,7 @@ void vdb_index::search_dev_locked(const float* d_q, size_t nq, size_t top_k, siz
     a.ef = (uint32_t)ef_; a.top_k = (uint32_t)top_k; a.out = d_out; a.out_n = d_out_n; a.stats = d_stats;
     if (fa && fa->bits) { a.pass_bits = fa->bits->d_pass.p; a.err_bits = fa->bits->d_err.p; }
     if (!a.stats) {                       // the kernels report per-query flags: one private array per stream
-        auto& buf = s_stats_by_stream[s];
+        auto& buf = stream_scratch(s).stats;
         buf.reserve(nq, s, false);
         a.stats = buf.p;
     }
@@ -740,7 +755,8 @@ void vdb_index::exact_knn(const float* q, size_t nq, size_t top_k, bool dev, vdb
     // FAST: MFMA candidate pass + strict re-rank; STRICT (and shapes the MFMA kernel does not take): every pair in strict arithmetic
     const bool mfma = opts.arith == VDB_ARITH_FAST && knn_mfma_supported(g, (uint32_t)top_k) && !std::getenv("VDB_KNN_STRICT");
     const uint32_t chunks = exact_knn_chunks(g.n);
-    DevBuf<uint32_t>& words = s_knn_words_by_stream[s]; DevBuf<vdb_scored_point>& lists = s_knn_by_stream[s];
+    StreamScratch& sc = stream_scratch(s);
+    DevBuf<uint32_t>& words = sc.knn_words; DevBuf<vdb_scored_point>& lists = sc.knn_lists;
     if (mfma) words.reserve(knn_mfma_scratch_words(g.n, (uint32_t)nq, g.stride), s, false);
     else lists.reserve(nq * chunks * top_k, s, false);
     // A graph over all rows answers first (a short beam): its k-th key bounds the true one, and the candidate pass that

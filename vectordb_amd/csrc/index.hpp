@@ -102,10 +102,14 @@ struct vdb_index {
     void* pinned(size_t bytes) const;
     mutable vdb::DevBuf<float> s_q, s_raw; mutable vdb::DevBuf<vdb_scored_point> s_out, s_cand;
     mutable vdb::DevBuf<uint32_t> s_n, s_slots, s_qslots, s_lvl, s_off, s_nb, s_nbc, s_bin, s_bout, s_hash, s_spill, s_spill_lit; mutable vdb::DevBuf<vdb_query_stats> s_stats;
-    mutable std::map<hipStream_t, vdb::DevBuf<vdb_query_stats>> s_stats_by_stream;
-    // exact k-NN scratch per stream: device-buffer calls return before their kernels have run, so calls on different
-    // streams must not share it
-    mutable std::map<hipStream_t, vdb::DevBuf<uint32_t>> s_knn_words_by_stream; mutable std::map<hipStream_t, vdb::DevBuf<vdb_scored_point>> s_knn_by_stream;
+    // Scratch per stream (per-query flags, exact k-NN candidates): device-buffer calls return before their kernels have
+    // run, so calls on different streams must not share it.  At most STREAM_SCRATCH_MAX streams are remembered; the
+    // least recently used entry goes after a device-wide synchronisation (its stream may no longer exist, so it cannot
+    // be waited for by handle).
+    struct StreamScratch { vdb::DevBuf<vdb_query_stats> stats; vdb::DevBuf<uint32_t> knn_words; vdb::DevBuf<vdb_scored_point> knn_lists; uint64_t last_used = 0; };
+    static constexpr size_t STREAM_SCRATCH_MAX = 16;
+    mutable std::map<hipStream_t, StreamScratch> s_by_stream; mutable uint64_t s_stream_clock = 0;
+    StreamScratch& stream_scratch(hipStream_t s) const;       // mu held
 
     vdb_index(vdb_metric metric, size_t m, size_t ef, size_t cap, size_t dim, const vdb_options& o);
     ~vdb_index();
@@ -181,6 +185,12 @@ struct vdb_segment {
     mutable std::mutex filter_mu;
     mutable std::map<std::string, std::shared_ptr<vdb::FilterBits>> filter_cache;
     mutable uint64_t filter_clock = 0;
+    // Bitmaps that launches queued on a caller's stream still read: held here, per stream, until an event recorded
+    // behind those launches has completed (checked on that stream's next call), whatever happens to the cache entry.
+    struct InFlight { std::shared_ptr<const vdb::FilterBits> bits; hipEvent_t done; };
+    mutable std::map<hipStream_t, std::vector<InFlight>> in_flight; mutable std::vector<hipEvent_t> spare_events;
+    void hold_until_done(std::shared_ptr<const vdb::FilterBits> bits, hipStream_t s) const;
+    ~vdb_segment();
 
     // payload columns and the bitmap of slots that own a payload: what the device-side filter compiler reads
     mutable std::map<std::string, vdb::PayloadColumn> columns;

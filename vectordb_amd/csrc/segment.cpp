@@ -695,7 +695,38 @@ void vdb_segment::search_batch_dev(const float* d_q, size_t nq, size_t top_k, si
         vdb_index::FilterArgs fa; fa.mode = MODE_MASKED; fa.bits = bits.get();
         h.search_batch_dev(d_q, nq, top_k, ef_search, d_out, d_out_n, d_stats, s, &fa);
     }
-    // the bitmaps must outlive the launches: the cache holds them, and an evicted entry is kept until the stream has drained
-    h.use_device();
-    if (bits.use_count() == 1) VDB_HIP(hipStreamSynchronize(s ? s : h.stream));
+    hold_until_done(bits, s ? s : h.stream);         // the bitmaps must outlive the launches
+}
+
+void vdb_segment::hold_until_done(std::shared_ptr<const FilterBits> bits, hipStream_t s) const {
+    hnsw->use_device();
+    std::lock_guard<std::mutex> lk(filter_mu);
+    for (auto it = in_flight.begin(); it != in_flight.end();) {      // launches of earlier calls that have finished, on any stream
+        std::vector<InFlight>& l = it->second;
+        size_t kept = 0;
+        for (size_t i = 0; i < l.size(); ++i) {
+            if (hipEventQuery(l[i].done) == hipSuccess) spare_events.push_back(l[i].done);
+            else { if (kept != i) l[kept] = std::move(l[i]); ++kept; }
+        }
+        l.resize(kept);
+        it = l.empty() && it->first != s ? in_flight.erase(it) : std::next(it);
+    }
+    std::vector<InFlight>& q = in_flight[s];
+    if (!q.empty() && q.back().bits == bits) {        // the same bitmaps again: move their event behind the new launches
+        VDB_HIP(hipEventRecord(q.back().done, s));
+        return;
+    }
+    hipEvent_t ev;
+    if (!spare_events.empty()) { ev = spare_events.back(); spare_events.pop_back(); }
+    else VDB_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    if (hipError_t e = hipEventRecord(ev, s); e != hipSuccess) { spare_events.push_back(ev); VDB_HIP(e); }
+    q.push_back(InFlight{std::move(bits), ev});
+}
+
+vdb_segment::~vdb_segment() {
+    if (in_flight.empty() && spare_events.empty()) return;
+    (void)hipSetDevice(hnsw->opts.device);
+    (void)hipDeviceSynchronize();
+    for (auto& [st, q] : in_flight) for (InFlight& f : q) (void)hipEventDestroy(f.done);
+    for (hipEvent_t e : spare_events) (void)hipEventDestroy(e);
 }
