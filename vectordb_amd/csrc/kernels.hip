@@ -91,13 +91,14 @@ __global__ void __launch_bounds__(256) scan_strict_kernel(const float* __restric
 // the block in one pass over the rows' registers.
 constexpr int SCAN_QH = 8, SCAN_QB = 1, SCAN_NB = 2;
 typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 // V partial sums per lane, to be summed over W adjacent lanes.  While more than one value is left a step halves the
 // values instead of repeating the exchange: the lane whose bit W/2 is set keeps the upper half and hands the lower half to
 // its partner, so V values cost about V exchanges instead of V log2(W).  Afterwards, with g the lane's position among
 // the G lanes the first call was made for: V >= G leaves a[0 .. V/G) = totals of values g * (V/G) + i; V < G leaves
 // a[0] = total of value g / (G/V) in every lane of that run.
-template <int V, int W>
+template <int V, int W, int STRIDE = 1>                  // STRIDE: distance in lanes between neighbours of the group
 __device__ __forceinline__ void fold_lanes(float* a, int g) {
     if constexpr (W > 1) {
         constexpr int M = W / 2;
@@ -107,12 +108,12 @@ __device__ __forceinline__ void fold_lanes(float* a, int g) {
             for (int i = 0; i < V / 2; ++i) {
                 const float send = up ? a[i] : a[i + V / 2];
                 const float keep = up ? a[i + V / 2] : a[i];
-                a[i] = keep + __shfl_xor(send, M, WAVE);
+                a[i] = keep + __shfl_xor(send, M * STRIDE, WAVE);
             }
-            fold_lanes<V / 2, M>(a, g);
+            fold_lanes<V / 2, M, STRIDE>(a, g);
         } else {
-            a[0] += __shfl_xor(a[0], M, WAVE);
-            fold_lanes<1, M>(a, g);
+            a[0] += __shfl_xor(a[0], M * STRIDE, WAVE);
+            fold_lanes<1, M, STRIDE>(a, g);
         }
     }
 }
@@ -167,9 +168,12 @@ __global__ void __launch_bounds__(256) scan_fast_kernel(const float* __restrict_
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const uint32_t r = min(r0 + rr * R + i, n - 1);   // rows past the end repeat the last one and are not written
-            const float4* row = reinterpret_cast<const float4*>(base + (size_t)r * stride);
+            const floatx4* row = reinterpret_cast<const floatx4*>(base + (size_t)r * stride);
 #pragma unroll
-            for (int j = 0; j < CH; ++j) dst[i][j] = row[min((uint32_t)(g + G * j), nchunks - 1)];   // unconditional: no predicated loads
+            for (int j = 0; j < CH; ++j) {                     // unconditional: no predicated loads; streamed: a row is read once
+                const floatx4 v = __builtin_nontemporal_load(row + min((uint32_t)(g + G * j), nchunks - 1));
+                dst[i][j] = make_float4(v[0], v[1], v[2], v[3]);
+            }
         }
     };
     auto score = [&](float4 (&x)[R][CH], uint32_t r0) {
@@ -278,6 +282,155 @@ __global__ void __launch_bounds__(256) scan_fast_kernel(const float* __restrict_
     }
 }
 
+// FAST scan of dot / cosine rows against a block of 3 .. 8 queries on the matrix cores: v_mfma_f32_4x4x1_16B_f32 is 16
+// independent outer products of 4 x 4 (full fp32 products and sums), here 4 rows x 4 queries at 16 places of the row.
+// A wavefront takes 4 rows per step: lane (b = lane / 4, i = lane % 4) loads the float4 at float4 position 16 p + b of
+// row i (256 contiguous bytes per row and load) for the PC positions p of a tile; each of its four floats is the A
+// operand of two MFMAs (queries 0..3 and 4..7), whose B operand -- lane (b, j): the same float of query j -- comes from
+// LDS, laid out so that a wavefront reads 1 KiB in lane order.  The 4 x 8 sums of a step take 8 accumulator registers
+// (64 in the vector kernel), which leaves room for the next tile's rows in flight while this one is multiplied; the
+// vector units only square the rows for the cosine norm and fold the 16 partial products of a sum at the end of a row.
+template <int PC, int RQ, bool COS>
+__global__ void __launch_bounds__(256) scan_mfma_kernel(const float* __restrict__ queries, uint32_t nq, const float* __restrict__ base,
+                                                       uint32_t n, uint32_t dim, uint32_t stride, uint32_t ntile, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* qf = reinterpret_cast<float*>(smem);                // [position][half][b][j] float4: query 4 half + j at float4 16 position + b; zero beyond the row and the block's queries
+    const float4* qb = reinterpret_cast<const float4*>(smem);
+    const uint32_t q0 = blockIdx.y * SCAN_Q;
+    const uint32_t qn = min((uint32_t)SCAN_Q, nq - q0);
+    const uint32_t nchunks = (dim + 3u) >> 2;                  // float4 per row
+    const uint32_t npos = ntile * PC;
+    for (uint32_t i = threadIdx.x; i < npos * 512; i += blockDim.x) {
+        const uint32_t comp = i & 3, j = (i >> 2) & 3, b = (i >> 4) & 15, half = (i >> 8) & 1, p = i >> 9;
+        const uint32_t d = (p * 16 + b) * 4 + comp, t = half * 4 + j;
+        qf[i] = (t < qn && d < dim) ? queries[(size_t)(q0 + t) * dim + d] : 0.f;
+    }
+    __syncthreads();
+    const int lane = lane_id(), b = lane >> 2, i4 = lane & 3;
+    // after the fold lane (b, j) holds the sum of row (b / 2) % 4 of its quad and query j + 4 (b / 8)
+    const int my_row = (b >> 1) & 3, my_q = i4 + 4 * (b >> 3);
+    float qnorm = 0.f;
+    if (COS) {                                                 // |query my_q|: each of the 8 lanes that share it sums 1/8
+        float a = 0.f;
+        for (uint32_t f = b & 7; f < npos * 16; f += 8) {
+            const float4 v = qb[((f >> 4) * 2 + (b >> 3)) * 64 + (f & 15) * 4 + i4];
+            a = __builtin_fmaf(v.x, v.x, a); a = __builtin_fmaf(v.y, v.y, a); a = __builtin_fmaf(v.z, v.z, a); a = __builtin_fmaf(v.w, v.w, a);
+        }
+        a += __shfl_xor(a, 4, WAVE); a += __shfl_xor(a, 8, WAVE); a += __shfl_xor(a, 16, WAVE);
+        qnorm = __builtin_sqrtf(a);
+    }
+    constexpr uint32_t RS = 4 * RQ;                            // rows per step: RQ quads of 4 rows share every read of the queries
+    constexpr uint32_t SPAN = 32, SPS = SPAN / RS;             // a wavefront takes spans of 32 consecutive rows: its results leave as whole 128-byte lines per query
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE, nwaves = gridDim.x * blockDim.x / WAVE;
+    const uint32_t nspans = (n + SPAN - 1) / SPAN;
+    if (wave >= nspans) return;
+    const uint32_t my_steps = (nspans - wave + nwaves - 1) / nwaves * SPS;
+    const uint32_t tiles = my_steps * ntile;
+    float* stage = qf + (size_t)npos * 512 + (threadIdx.x / WAVE) * (SCAN_Q * SPAN);      // [query][row of the span], this wavefront's own
+    const bool wide = (n % 4 == 0) && ((uintptr_t)out % 16 == 0);
+    auto row_of = [&](uint32_t step) { return (wave + (step / SPS) * nwaves) * SPAN + (step % SPS) * RS; };
+
+    auto fetch = [&](float4 (&a)[RQ][PC], uint32_t step, uint32_t c) {
+#pragma unroll
+        for (int r = 0; r < RQ; ++r) {
+            const uint32_t row = min(row_of(step) + 4u * r + (uint32_t)i4, n - 1);   // rows past the end repeat the last one and are not written
+            const floatx4* p = reinterpret_cast<const floatx4*>(base + (size_t)row * stride);
+#pragma unroll
+            for (int g = 0; g < PC; ++g) {                     // unconditional: no predicated loads; streamed: a row is read once
+                const floatx4 v = __builtin_nontemporal_load(p + min((c * PC + g) * 16u + (uint32_t)b, nchunks - 1));
+                a[r][g] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    };
+    // The results of a span leave one tile late, right after the next tile's loads were issued: the memory counter of a
+    // wavefront retires in order, so a store issued before those loads would have to be acknowledged before the tile
+    // after it can be multiplied.
+    float4 pend_v = make_float4(0.f, 0.f, 0.f, 0.f); uint32_t pend_row = 0; bool pending = false;
+    auto flush = [&]() {
+        if (!pending) return;                                  // uniform
+        pending = false;
+        const uint32_t t = (uint32_t)lane >> 3, row = pend_row;
+        if (t < qn && row < n) {
+            float* o = out + (size_t)(q0 + t) * n + row;
+            if (wide) __builtin_nontemporal_store(floatx4{pend_v.x, pend_v.y, pend_v.z, pend_v.w}, reinterpret_cast<floatx4*>(o));
+            else { o[0] = pend_v.x; if (row + 1 < n) o[1] = pend_v.y; if (row + 2 < n) o[2] = pend_v.z; if (row + 3 < n) o[3] = pend_v.w; }
+        }
+    };
+    floatx4 lo[RQ], hi[RQ];                                    // [quad][row] of query i4 / i4 + 4, the part of place b
+    floatx2 ss[RQ];
+#pragma unroll
+    for (int r = 0; r < RQ; ++r) { lo[r] = floatx4{0.f, 0.f, 0.f, 0.f}; hi[r] = floatx4{0.f, 0.f, 0.f, 0.f}; ss[r] = floatx2{0.f, 0.f}; }
+    auto multiply = [&](float4 (&a)[RQ][PC], uint32_t step, uint32_t c) {
+        if ((c + 1) * PC * 16u > nchunks) {                    // uniform: only the last tile of a row can run past its end
+#pragma unroll
+            for (int g = 0; g < PC; ++g)
+                if ((c * PC + g) * 16u + (uint32_t)b >= nchunks) {
+#pragma unroll
+                    for (int r = 0; r < RQ; ++r) a[r][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+        }
+        const float4* bq = qb + (size_t)c * PC * 128 + lane;
+#pragma unroll
+        for (int g = 0; g < PC; ++g) {
+            const float4 bl = bq[g * 128], bh = bq[g * 128 + 64];
+#pragma unroll
+            for (int r = 0; r < RQ; ++r) {
+                const float4 x = a[r][g];
+                lo[r] = __builtin_amdgcn_mfma_f32_4x4x1f32(x.x, bl.x, lo[r], 0, 0, 0); hi[r] = __builtin_amdgcn_mfma_f32_4x4x1f32(x.x, bh.x, hi[r], 0, 0, 0);
+                lo[r] = __builtin_amdgcn_mfma_f32_4x4x1f32(x.y, bl.y, lo[r], 0, 0, 0); hi[r] = __builtin_amdgcn_mfma_f32_4x4x1f32(x.y, bh.y, hi[r], 0, 0, 0);
+                lo[r] = __builtin_amdgcn_mfma_f32_4x4x1f32(x.z, bl.z, lo[r], 0, 0, 0); hi[r] = __builtin_amdgcn_mfma_f32_4x4x1f32(x.z, bh.z, hi[r], 0, 0, 0);
+                lo[r] = __builtin_amdgcn_mfma_f32_4x4x1f32(x.w, bl.w, lo[r], 0, 0, 0); hi[r] = __builtin_amdgcn_mfma_f32_4x4x1f32(x.w, bh.w, hi[r], 0, 0, 0);
+                if (COS) {
+                    const floatx2 va{x.x, x.y}, vb{x.z, x.w};
+                    ss[r] = __builtin_elementwise_fma(va, va, ss[r]); ss[r] = __builtin_elementwise_fma(vb, vb, ss[r]);
+                }
+            }
+        }
+        if (c + 1 != ntile) return;
+        // the rows' sums are complete in 16 parts (one per b): fold them over b
+#pragma unroll
+        for (int r = 0; r < RQ; ++r) {
+            float v[8] = {lo[r][0], lo[r][1], lo[r][2], lo[r][3], hi[r][0], hi[r][1], hi[r][2], hi[r][3]};
+            fold_lanes<8, 16, 4>(v, b);                        // every lane: the sum of value b / 2
+            float raw = v[0];
+            if (COS) {
+                float t = ss[r].x + ss[r].y;                   // |row i4 of the quad|^2, the part of place b
+                t += __shfl_xor(t, 4, WAVE); t += __shfl_xor(t, 8, WAVE); t += __shfl_xor(t, 16, WAVE); t += __shfl_xor(t, 32, WAVE);
+                const float xv = __builtin_sqrtf(__shfl(t, my_row, WAVE));
+                raw = 1.0f - raw / (qnorm * xv + 1e-10f);
+            }
+            if ((b & 1) == 0) stage[my_q * SPAN + (step % SPS) * RS + 4 * r + my_row] = raw;
+            lo[r] = floatx4{0.f, 0.f, 0.f, 0.f}; hi[r] = floatx4{0.f, 0.f, 0.f, 0.f}; ss[r] = floatx2{0.f, 0.f};
+        }
+        if (step % SPS != SPS - 1) return;
+        // the span is complete: lane l writes rows 4 (l % 8) .. + 3 of query l / 8
+        wave_sync();
+        const float4 v4 = reinterpret_cast<const float4*>(stage)[lane];
+        wave_sync();
+        pend_v = v4; pend_row = row_of(step - (SPS - 1)) + 4u * ((uint32_t)lane & 7); pending = true;
+    };
+    // two tile buffers in turn: the next tile's rows are in flight while this one is multiplied
+    float4 xa[RQ][PC], xb[RQ][PC];
+    uint32_t step = 0, c = 0;
+    auto next = [&](uint32_t& s2, uint32_t& c2) { c2 = c + 1; s2 = step; if (c2 == ntile) { c2 = 0; s2 = min(step + 1, my_steps - 1); } };
+    fetch(xa, 0, 0);
+    for (uint32_t t = 0; t < tiles; t += 2) {
+        uint32_t s2, c2;
+        next(s2, c2);
+        fetch(xb, s2, c2);                                     // past the last tile: a repeat of valid rows, never multiplied
+        flush();
+        multiply(xa, step, c);
+        if (t + 1 >= tiles) break;
+        step = c2 == 0 ? step + 1 : step; c = c2;
+        next(s2, c2);
+        fetch(xa, s2, c2);
+        flush();
+        multiply(xb, step, c);
+        step = c2 == 0 ? step + 1 : step; c = c2;
+    }
+    flush();
+}
+
 __global__ void __launch_bounds__(64) score_rows_kernel(GraphView gv, uint32_t query_slot, const uint32_t* __restrict__ slots, uint32_t n, float* __restrict__ raw) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) raw[i] = strict_pair(gv.vecs + (size_t)query_slot * gv.stride, gv.vecs + (size_t)slots[i] * gv.stride, gv.dim, gv.metric, false);
@@ -316,6 +469,25 @@ void launch_score_scan(const float* queries, uint32_t nq, const float* base, uin
         }
         const uint32_t blocks = std::min<uint32_t>((n + 255) / 256, 256 * 8);
         hipLaunchKernelGGL(scan_strict_kernel, dim3(blocks, qblocks), dim3(256), lds, st, queries, nq, base, n, dim, stride, metric, out);
+    } else if (metric != VDB_EUCLIDEAN && nq >= 5 && qpad >= 320 && !std::getenv("VDB_SCAN_NO_MFMA")) {
+        // dot / cosine rows of more than 256 floats against a block of 5 .. 8 queries: the matrix-core kernel (measured
+        // against the vector kernel on 1M rows: faster from 5 queries and from rows of 384 floats on, equal at 256).
+        // Tiles of PC places of 16 float4, PC chosen for the least padding of the row.
+        const uint32_t npos = (qpad / 4 + 15) / 16;
+        const uint32_t pc = (npos + 2) / 3 * 3 - npos <= (npos + 1) / 2 * 2 - npos ? 3u : 2u;
+        const uint32_t ntile = (npos + pc - 1) / pc;
+        lds = (size_t)ntile * pc * 2048 + 4 * SCAN_Q * 32 * sizeof(float);          // the queries, then a staging area of the results per wavefront
+        int dev = 0, cus = 0;
+        VDB_HIP(hipGetDevice(&dev));
+        VDB_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        // one launch of resident blocks: every wavefront walks its share of the rows
+#define VDB_SCAN_M(PC, COS) do { int per_cu = 0; VDB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, scan_mfma_kernel<PC, 4, COS>, 256, lds)); \
+                                 const dim3 grid((uint32_t)(cus * std::max(per_cu, 1)), qblocks); \
+                                 hipLaunchKernelGGL((scan_mfma_kernel<PC, 4, COS>), grid, dim3(256), lds, st, queries, nq, base, n, dim, stride, ntile, out); } while (0)
+#define VDB_SCAN_MC(PC) do { if (metric == VDB_COSINE) VDB_SCAN_M(PC, true); else VDB_SCAN_M(PC, false); } while (0)
+        if (pc == 3) VDB_SCAN_MC(3); else VDB_SCAN_MC(2);
+#undef VDB_SCAN_MC
+#undef VDB_SCAN_M
     } else {
         const uint32_t chunks = qpad / 4;
         const uint32_t blocks = 256 * 8;

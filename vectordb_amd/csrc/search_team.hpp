@@ -6,7 +6,7 @@
 // Every wavefront of the team takes a share of the step's parents (parent i goes to wavefront i mod TW): it fetches
 // their adjacency blocks, tests their neighbours against the visited table the team shares in LDS, scores the unvisited
 // rows' slots into a pool in LDS; every wavefront then scores an equal share of the pool and wavefront 0 merges it.
-// Four workgroup barriers per step: parents / counts / pool / scores published.  A step expands up to 4 x TW nodes; expanding w nodes per step in total is the same walk as the
+// Four workgroup barriers per step: parents / counts / pool / scores published (one more per round of a hub's overflow chunks).  A step expands up to 4 x TW nodes; expanding w nodes per step in total is the same walk as the
 // one-wavefront beam at width w (the candidates of a step reach the list in wavefront order instead of parent order,
 // which only orders exactly equal keys differently).
 // The upper-layer descent makes the same moves as greedy_fused(): every wavefront reads the current node's block, the
@@ -199,6 +199,7 @@ struct TeamSearcher : Searcher<MODE_SEARCH, G, CH, PASSES, false, METRIC, NC> {
         if (width > (uint32_t)(EMAX * TW)) width = EMAX * TW;
         if (width == 0) width = 1;
         // the beam's candidates live in one pool shared by the team: TW * SEG slots followed by as many scores
+        __syncthreads();                                                  // the descent used one segment per wavefront: nobody is still reading its own
         cand = segs; craw = reinterpret_cast<float*>(segs + (size_t)TW * SEG);
         if (wv == 0) {
             uint32_t start = entry;
@@ -349,7 +350,7 @@ struct TeamSearcher : Searcher<MODE_SEARCH, G, CH, PASSES, false, METRIC, NC> {
                     VDB_T_MARK(4);
                 }
                 if (total_hub == 0) break;
-                if (total) __syncthreads();                               // the merge has read the pool
+                __syncthreads();                                          // the merge has read the pool, every wavefront the counts: both are written again below
                 m = 0;
 #pragma unroll
                 for (int e = 0; e < EMAX; ++e) fresh[e] = false;
