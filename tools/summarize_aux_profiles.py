@@ -1,6 +1,6 @@
 """Turns the raw rocprofv3 output of tools/collect_aux_profiles.sh (gpurun_out/aux_<tag>/) into the committed
 summaries profiles/<tag>_exact_knn.json, profiles/<tag>_scan.json and the kernel-stats tables beside them."""
-import glob, json, os, sys
+import glob, json, os, re, sys
 import pandas as pd
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
@@ -50,15 +50,15 @@ f = counters("scan_fetch", "scan_"); w = counters("scan_write", "scan_")
 k8 = ss[ss.Name.str.contains("scan_", regex=False)].iloc[0]; k1 = ss1[ss1.Name.str.contains("scan_", regex=False)].iloc[0]
 hbm = (2 * f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024
 scan = {"command": f"tools/collect_aux_profiles.sh {tag}", "eight_queries": s8, "one_query": s1,
-        "kernel": k8.Name.split("(")[0], "avg_us_8_queries": k8.AverageNs / 1e3, "avg_us_1_query": k1.AverageNs / 1e3,
+        "kernel": re.search(r"scan_\w+<[^>]*>", k8.Name).group(0), "avg_us_8_queries": k8.AverageNs / 1e3, "avg_us_1_query": k1.AverageNs / 1e3,
         "algorithmic_GBps_8_queries": s8["algorithmic_bytes"] / (k8.AverageNs / 1e3) / 1e3, "algorithmic_GBps_1_query": s1["algorithmic_bytes"] / (k1.AverageNs / 1e3) / 1e3,
         "FETCH_SIZE_KB": f["FETCH_SIZE"], "WRITE_SIZE_KB": w["WRITE_SIZE"],
         "correction": "gfx950 FETCH_SIZE counts 64 B per 128-B request of a 16-B-per-lane read, so it is doubled; WRITE_SIZE is taken as is",
         "hbm_bytes_per_launch_8_queries": hbm, "traffic_over_algorithmic": hbm / s8["algorithmic_bytes"]}
 if glob.glob(f"{src}/scan_l2_trace/*/*_kernel_stats.csv"):
     sl = pd.read_csv(newest(f"{src}/scan_l2_trace/*/*_kernel_stats.csv")); kl = sl[sl.Name.str.contains("scan_", regex=False)].iloc[0]; bl = last_json(f"{src}/scan_l2_trace.json")
-    scan["eight_queries_l2"] = {"kernel": kl.Name.split("(")[0], "avg_us": kl.AverageNs / 1e3, "bench": bl, "frac_of_8TBps": bl["algorithmic_bytes"] / (kl.AverageNs / 1e3) / 1e3 / 8000}
-scan["kernel_1_query"] = k1.Name.split("(")[0]
+    scan["eight_queries_l2"] = {"kernel": re.search(r"scan_\w+<[^>]*>", kl.Name).group(0), "avg_us": kl.AverageNs / 1e3, "bench": bl, "frac_of_8TBps": bl["algorithmic_bytes"] / (kl.AverageNs / 1e3) / 1e3 / 8000}
+scan["kernel_1_query"] = re.search(r"scan_\w+<[^>]*>", k1.Name).group(0)
 scan["frac_of_8TBps_8_queries"] = scan["algorithmic_GBps_8_queries"] / 8000; scan["frac_of_8TBps_1_query"] = scan["algorithmic_GBps_1_query"] / 8000
 json.dump(scan, open(f"profiles/{tag}_scan.json", "w"), indent=1)
 print(json.dumps(knn["candidate_pass_128"], indent=1)); print(json.dumps({k: v for k, v in scan.items() if not isinstance(v, dict)}, indent=1))
