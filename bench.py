@@ -239,6 +239,7 @@ def main():
     lanes = [(stream, d_out, d_n, d_stats)]
     for _ in range(n_streams - 1):
         lanes.append((torch.cuda.Stream(device=dev), torch.zeros_like(d_out), torch.zeros_like(d_n), torch.zeros_like(d_stats)))
+    xstream = torch.cuda.Stream(device=dev) if exchange else None
     searched = [torch.cuda.Event() for _ in lanes]      # search of the lane's current step is enqueued
     merged_ev = [None for _ in lanes]                   # the exchange that last read the lane's buffers
 
@@ -253,13 +254,14 @@ def main():
             lane[0].wait_event(merged_ev[li])           # the previous exchange has consumed these buffers
         launch(lane, 0 if replay else i % NB)
         if exchange:
-            # exchange + merge on torch's current stream, ordered after this lane's search by an
-            # event (no host synchronisation): the next step's search overlaps it on the other lane
+            # exchange + merge on a stream of their own, ordered after this lane's search by an event (no host
+            # synchronisation): the next step's search overlaps it on the other lane.  Not the null stream: whatever is
+            # recorded there also waits for the other lane's running search, and the lanes fall into lockstep.
             searched[li].record(lane[0])
-            cur = torch.cuda.current_stream(dev)
-            cur.wait_event(searched[li])
-            merged(lane[1], lane[2])
-            merged_ev[li] = torch.cuda.Event(); merged_ev[li].record(cur)
+            xstream.wait_event(searched[li])
+            with torch.cuda.stream(xstream):
+                merged(lane[1], lane[2])
+            merged_ev[li] = torch.cuda.Event(); merged_ev[li].record(xstream)
 
     # (A) back to back on ONE stream, HIP events on that stream: the kernel's own average duration
     def lone(replay):

@@ -162,8 +162,17 @@ class ShardedIndex:
         if not gathered and self.vgroup:            # RCCL all-gather + merge kernel inside the library, on torch's current stream
             m_out = torch.empty(nq * k * 16, dtype=torch.uint8, device=d_out.device)
             m_cnt = torch.empty(nq, dtype=torch.int32, device=d_out.device)
-            cur = torch.cuda.current_stream(d_out.device).cuda_stream
-            self.api.check(self.api.fn.shard_exchange_dev(self.vgroup, d_out.data_ptr(), d_cnt.data_ptr(), nq, k, m_out.data_ptr(), m_cnt.data_ptr(), cur))
+            cur = torch.cuda.current_stream(d_out.device)
+            if cur.cuda_stream == 0:
+                # the collective's copies on the null stream wait for every other stream of the device (measured: a search
+                # queued on another stream no longer overlaps the exchange): run it on a stream of this object's own,
+                # ordered after and before the null stream
+                if not hasattr(self, "_stream"): self._stream = torch.cuda.Stream(device=d_out.device)
+                self._stream.wait_stream(cur)
+                self.api.check(self.api.fn.shard_exchange_dev(self.vgroup, d_out.data_ptr(), d_cnt.data_ptr(), nq, k, m_out.data_ptr(), m_cnt.data_ptr(), self._stream.cuda_stream))
+                cur.wait_stream(self._stream)
+            else:
+                self.api.check(self.api.fn.shard_exchange_dev(self.vgroup, d_out.data_ptr(), d_cnt.data_ptr(), nq, k, m_out.data_ptr(), m_cnt.data_ptr(), cur.cuda_stream))
             return m_out, m_cnt
         if not gathered:
             import torch.distributed as dist
