@@ -5,6 +5,7 @@ use std::os::raw::{c_char, c_double, c_int, c_void};
 
 #[repr(C)] pub struct vdb_index { _p: [u8; 0] }
 #[repr(C)] pub struct vdb_segment { _p: [u8; 0] }
+#[repr(C)] pub struct vdb_shard_group { _p: [u8; 0] }
 #[repr(C)] pub struct vdb_value { _p: [u8; 0] }
 #[repr(C)] pub struct vdb_payload { _p: [u8; 0] }
 #[repr(C)] pub struct vdb_filter { _p: [u8; 0] }
@@ -146,4 +147,14 @@ extern "C" {
     pub fn vdb_segment_compile_filter(s: *const vdb_segment, f: *const vdb_filter, n_pass: *mut usize, n_err: *mut usize) -> c_int;
     pub fn vdb_segment_filter_bitmaps(s: *const vdb_segment, f: *const vdb_filter, pass: *mut u32, err: *mut u32, cap_words: usize) -> c_int;
     pub fn vdb_topk_merge_dev(d_lists: *const vdb_scored_point, d_counts: *const u32, n_shards: usize, nq: usize, k: usize, d_out: *mut vdb_scored_point, d_out_n: *mut u32, stream: *mut c_void) -> c_int;
+    // scale-out: one shard per rank, one RCCL communicator per group (include/vdbmi.h, shard group section)
+    pub fn vdb_shard_group_unique_id(out: *mut c_void, cap: usize) -> c_int;
+    pub fn vdb_shard_group_new(unique_id: *const c_void, id_bytes: usize, rank: c_int, world: c_int, device: c_int, out: *mut *mut vdb_shard_group) -> c_int;
+    pub fn vdb_shard_group_free(g: *mut vdb_shard_group);
+    pub fn vdb_shard_group_size(g: *const vdb_shard_group) -> c_int;
+    pub fn vdb_shard_group_rank(g: *const vdb_shard_group) -> c_int;
+    pub fn vdb_shard_exchange_dev(g: *mut vdb_shard_group, d_lists: *const vdb_scored_point, d_counts: *const u32, nq: usize, k: usize, d_out: *mut vdb_scored_point, d_out_n: *mut u32, stream: *mut c_void) -> c_int;
+    pub fn vdb_shard_search_batch_dev(g: *mut vdb_shard_group, x: *const vdb_index, d_q: *const f32, nq: usize, top_k: usize, ef_search: usize, d_out: *mut vdb_scored_point, d_out_n: *mut u32, stream: *mut c_void) -> c_int;
+    pub fn vdb_shard_exact_knn_batch_dev(g: *mut vdb_shard_group, x: *const vdb_index, d_q: *const f32, nq: usize, top_k: usize, d_out: *mut vdb_scored_point, d_out_n: *mut u32, stream: *mut c_void) -> c_int;
+    pub fn vdb_shard_segment_search_batch_dev(g: *mut vdb_shard_group, s: *const vdb_segment, d_q: *const f32, nq: usize, top_k: usize, ef_search: usize, f: *const vdb_filter, d_out: *mut vdb_scored_point, d_out_n: *mut u32, stream: *mut c_void) -> c_int;
 }

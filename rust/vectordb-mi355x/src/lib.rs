@@ -5,6 +5,7 @@
 //! the host-side mirrors the API hands out by reference (`get_vector`, `payloads`, `payload_index`).
 pub mod ffi;
 pub mod segment;
+pub mod shard;
 pub mod vector;
 
 pub use vectordb::payload_storage;

@@ -70,6 +70,10 @@ pub mod segment {
     }
     unsafe impl Send for Segment {}
     impl Drop for Segment { fn drop(&mut self) { unsafe { ffi::vdb_segment_free(self.s) } } }
+    impl Segment {
+        /// The library's handle, for the sharded entry points (crate::shard).
+        pub(crate) fn raw(&self) -> *const ffi::vdb_segment { self.s }
+    }
 
     type Call = unsafe extern "C" fn(*const ffi::vdb_segment, *const f32, usize, usize, *const ffi::vdb_filter, *mut ffi::vdb_scored_point, *mut usize) -> i32;
 
