@@ -81,6 +81,9 @@ vdb_status vdb_score_scan_dev(const float* d_queries, size_t nq, const float* d_
                               vdb_arith arith, float* d_out, void* stream) {
     return guard([&] {
         need(d_queries, "d_queries"); need(d_base, "d_base"); need(d_out, "d_out");
+        if (dim == 0) throw Failure(err_arg("dim must be positive"));
+        if (stride < dim) throw Failure(err_arg("the row stride is shorter than the rows"));
+        if (n > 0xFFFFFFFFull || nq > 0xFFFFFFFFull || stride > 0xFFFFFFFFull) throw Failure(err_arg("more than 2^32 - 1 rows, queries or floats per row in one scan"));
         launch_score_scan(d_queries, (uint32_t)nq, d_base, (uint32_t)n, (uint32_t)dim, (uint32_t)stride, (int)metric, (int)arith, d_out, (hipStream_t)stream);
     });
 }
