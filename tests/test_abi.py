@@ -36,3 +36,12 @@ def test_no_gpu_means_loud_failure(vdb):
         vdb.HNSWIndex(vdb.DistanceMetric.Euclidean, 16, 64, 16, 4)
     with pytest.raises(vdb.DeviceError):
         vdb.score([1.0, 2.0], [3.0, 4.0], vdb.DistanceMetric.Dot)
+
+
+def test_the_device_buffer_scan_refuses_impossible_shapes_before_it_touches_a_device(vdb):
+    """vdb_score_scan_dev checks its sizes on the host: a stride shorter than the rows would read past every row."""
+    import pytest
+    p = 4096                                                   # never dereferenced: the call is refused first
+    for nq, n, dim, stride in ((1, 10, 0, 4), (1, 10, 8, 4), (1, 1 << 32, 8, 8), (1 << 32, 10, 8, 8)):
+        with pytest.raises(vdb.ArgumentError):
+            vdb.check(vdb.fn.score_scan_dev(p, nq, p, n, dim, stride, int(vdb.DistanceMetric.Dot), int(vdb.Arith.Fast), p, None))
