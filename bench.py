@@ -368,6 +368,11 @@ def main():
         result["config"]["id_agreement_with_oracle"] = round(agree, 5)          # this rank's shard, before the exchange
         if world == 1:
             result["config"]["oracle_recall_at_10"] = round(recall_at_k(ref, refn, exact[:nqc], K), 4)
+            result["config"]["oracle_recall_note"] = "the oracle's sequential search on the graph this run built on the GPU (same graph, same queries, same ef)"
+            if args.config == "c5":
+                result["config"]["recall_note"] = ("recall of a 12.5M-row shard levels off below 0.95 with the reference's linking rule (M nearest, no diversity rule): "
+                                                   "at 4M x 96 the oracle's point-by-point build and the batched GPU build follow the same curve within 0.5 pt "
+                                                   "(profiles/r03_c5_plateau_4m_96_oracle.log, profiles/r03_c5_plateau_4m_96_gpu.log)")
         if with_cpu:
             cores = os.cpu_count() or 1
             result["cpu_baseline"] = {"value": nqc / cpu_s, "unit": "queries/s", "cores": 1, "kind": "port",
