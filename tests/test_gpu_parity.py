@@ -24,7 +24,7 @@ def rel_close(a, b, tol=REL):
     return np.all(np.abs(a - b) <= tol * np.maximum(1e-6, np.maximum(np.abs(a), np.abs(b))))
 
 
-@pytest.mark.parametrize("dim", [1, 3, 4, 5, 32, 96, 128, 130, 324, 768, 960, 1000])
+@pytest.mark.parametrize("dim", [1, 3, 4, 5, 32, 96, 128, 130, 324, 768, 960, 1000, 1920, 2048])
 @pytest.mark.parametrize("metric", [0, 1, 2])
 def test_score_scan_strict_bitwise_and_fast_close(ora, vdb, dim, metric):
     q = data(9, dim, 1); b = data(257, dim, 2)

@@ -469,9 +469,10 @@ void launch_score_scan(const float* queries, uint32_t nq, const float* base, uin
         }
         const uint32_t blocks = std::min<uint32_t>((n + 255) / 256, 256 * 8);
         hipLaunchKernelGGL(scan_strict_kernel, dim3(blocks, qblocks), dim3(256), lds, st, queries, nq, base, n, dim, stride, metric, out);
-    } else if (metric != VDB_EUCLIDEAN && nq >= 5 && qpad >= 320 && !std::getenv("VDB_SCAN_NO_MFMA")) {
+    } else if (metric != VDB_EUCLIDEAN && nq >= 5 && qpad >= 320 && qpad <= 1920 && !std::getenv("VDB_SCAN_NO_MFMA")) {
         // dot / cosine rows of more than 256 floats against a block of 5 .. 8 queries: the matrix-core kernel (measured
         // against the vector kernel on 1M rows: faster from 5 queries and from rows of 384 floats on, equal at 256).
+        // Up to 1920 floats per row the eight queries and the staging area fit 64 KiB of LDS; longer rows stay on the vector kernel.
         // Tiles of PC places of 16 float4, PC chosen for the least padding of the row.
         const uint32_t npos = (qpad / 4 + 15) / 16;
         const uint32_t pc = (npos + 2) / 3 * 3 - npos <= (npos + 1) / 2 * 2 - npos ? 3u : 2u;
