@@ -95,5 +95,5 @@ cnt = {"kernel": main_name, "kernel_sources_sha256_16": kernel_sources_hash(), "
                    "share_of_wave_cycles_issue_stalled (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES)": sq2["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"],
                    "clock_GHz (GRBM_GUI_ACTIVE / 8 XCDs / kernel time)": gr["GRBM_GUI_ACTIVE"] / 8 / lone_us / 1e3,
                    "lds_bank_conflict_share (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE)": sq2["SQ_LDS_BANK_CONFLICT"] / sq2["SQ_LDS_IDX_ACTIVE"]}}
-json.dump(cnt, open(f"profiles/{tag}_search_kernel_sq_counters.json", "w"), indent=1)
+json.dump(cnt, open(f"profiles/{tag}_search_kernel_sq_counters.json" if cfg == "c2" else f"profiles/{tag}_search_kernel_{cfg}_sq_counters.json", "w"), indent=1)
 print(json.dumps(out, indent=1)); print(json.dumps(cnt["derived"], indent=1))
